@@ -1,0 +1,293 @@
+/*
+ * ptr_api.h — C-ABI of the MI355X-native per-ray hot path ("ptr" = path-tracer runtime).
+ *
+ * This is the drop-in boundary for felpzOliveira/PathTracer's render path.  The
+ * reference has no FFI: its host code (src/main.cpp render(), src/core/scene.cpp)
+ * launches CUDA kernels directly on managed memory.  Every entry point below names
+ * the reference launch site / host function it replaces (paths relative to the
+ * reference tree).  Signatures use plain pointers and sizes only.
+ *
+ * Data crossing the boundary is a *flat scene*: the reference's POD descriptors
+ * (src/core/scene.h:11-86) with every pointer-to-object replaced by an index or a
+ * plain array.  The library owns everything it uploads; the caller keeps ownership
+ * of every array it passes in (they may be freed after ptr_scene_upload returns).
+ */
+#ifndef PTR_API_H
+#define PTR_API_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTR_OK 0
+#define PTR_ERR_INVALID 1   /* bad argument / scene description            */
+#define PTR_ERR_HIP 2       /* a HIP runtime call failed                   */
+#define PTR_ERR_STATE 3     /* call order violated (e.g. render w/o scene) */
+#define PTR_ERR_LIMIT 4     /* a documented limit was exceeded             */
+
+#define PTR_MAX_TEXTURES 16 /* MaterialDescriptor::textures[16], scene.h:63 */
+#define PTR_MAX_LIGHTS 256  /* Aggregator::lightList[256], primitive.h:93   */
+
+/* ShapeType, src/core/shape.h:8-11 (same numeric values) */
+enum {
+    PTR_SHAPE_SPHERE = 0,
+    PTR_SHAPE_RECTANGLE = 1,
+    PTR_SHAPE_DISK = 2,
+    PTR_SHAPE_BOX = 3, /* dead in the reference: MakeShape builds BOX_PROCEDURAL, scene.cpp:746 */
+    PTR_SHAPE_MESH = 4,
+    PTR_SHAPE_PARTICLECLOUD = 5,
+    PTR_SHAPE_SPHERE_PROCEDURAL = 6,
+    PTR_SHAPE_BOX_PROCEDURAL = 7,
+    PTR_SHAPE_COMPONENT_PROCEDURAL = 8
+};
+
+/* MaterialType, src/core/material.h:250-254 (same numeric values) */
+enum {
+    PTR_MAT_NONE = 0,
+    PTR_MAT_MATTE = 1,
+    PTR_MAT_MIRROR = 2,
+    PTR_MAT_GLASS = 3,
+    PTR_MAT_METAL = 4,
+    PTR_MAT_TRANSLUCENT = 5,
+    PTR_MAT_PLASTIC = 6,
+    PTR_MAT_UBER = 7,
+    PTR_MAT_SUBSURFACE = 8,
+    PTR_MAT_KDSUBSURFACE = 9,
+    PTR_MAT_PLAYGROUND = 10
+};
+
+/* Integrator selector: the reference picks one by editing src/main.cpp:444-447 */
+enum {
+    PTR_LI_DIRECT = 0,      /* Li_Direct      main.cpp:72  */
+    PTR_LI_PATH = 1,        /* Li_Path        main.cpp:362 */
+    PTR_LI_PATHSAMPLED = 2, /* Li_PathSampled main.cpp:251 */
+    PTR_LI_VOLPATH = 3      /* Li_VolPath     main.cpp:105 */
+};
+
+/* Transform{Matrix4x4 m, mInv}, src/core/transform.h:8-49; row-major m[r*4+c] */
+typedef struct {
+    float m[16];
+    float mInv[16];
+} PtrTransform;
+
+/* TextureDescriptor, scene.h:52-57: type 0 = constant Spectrum, 1 = constant Float,
+ * 2 = image (index into PtrFlatScene::images) */
+typedef struct {
+    int32_t type;
+    float spec[3];
+    float fval;
+    int32_t image;
+} PtrTexture;
+
+/* MaterialDescriptor, scene.h:59-66.  Slot order per material type is the one
+ * MakeMaterial reads (scene.cpp:801-889). */
+typedef struct {
+    int32_t type; /* PTR_MAT_* */
+    int32_t is_emissive;
+    int32_t n_textures; /* slots filled (specs_taken for PlayGround) */
+    int32_t id;
+    PtrTexture textures[PTR_MAX_TEXTURES];
+    float vals[16];
+} PtrMaterial;
+
+/* MediumDescriptor, scene.h:68-72 */
+typedef struct {
+    float sigma_a[3];
+    float sigma_s[3];
+    float g;
+    int32_t is_valid;
+} PtrMedium;
+
+/* PrimitiveDescriptor, scene.h:74-86, with the per-shape descriptors folded into
+ * one parameter block:
+ *   SPHERE / SPHERE_PROCEDURAL : params[0]=radius
+ *   RECTANGLE                  : params[0]=sizex, [1]=sizey
+ *   DISK                       : params[0]=height, [1]=radius, [2]=innerRadius, [3]=phiMax(deg)
+ *   BOX_PROCEDURAL             : params[0..2]=sizex,sizey,sizez
+ *   COMPONENT_PROCEDURAL       : params[0..2]=bound.pMin, [3..5]=bound.pMax; geom=toy id
+ *   MESH                       : geom = index into meshes (to_world unused: the mesh carries it)
+ *   PARTICLECLOUD              : geom = index into clouds
+ */
+typedef struct {
+    int32_t shape_type;
+    int32_t reverse_orientation;
+    int32_t geom;
+    int32_t no_mat; /* medium-boundary primitive without material, scene.cpp:686-701 */
+    PtrTransform to_world;
+    float params[8];
+    PtrMaterial mat;
+    PtrMedium medium; /* interior medium (MediumInterface(medium, nullptr), scene.cpp:942) */
+} PtrPrimitive;
+
+/* ParsedMesh, src/core/shape.h:167-176.  p is in OBJECT space; the library applies
+ * to_world to its own copy (the reference mutates the caller's array, mesh.cpp:55-65).
+ * indices: 3 ints per corner {position, normal, uv} = 9 ints per triangle (shape.h:178-183). */
+typedef struct {
+    int32_t n_triangles, n_vertices, n_uvs;
+    int32_t _pad;
+    const float *p;         /* 3 * n_vertices */
+    const int32_t *indices; /* 9 * n_triangles */
+    const float *uv;        /* 2 * n_uvs or NULL */
+    PtrTransform to_world;
+} PtrMesh;
+
+/* ParticleCloudDescripor, scene.h:40-44 */
+typedef struct {
+    int32_t n_particles;
+    float radius;
+    const float *positions; /* 3 * n_particles */
+} PtrCloud;
+
+/* ImageData, src/core/texture.h:10-16 */
+typedef struct {
+    int32_t width, height;
+    const float *rgb; /* 3 * width * height, linear floats as loaded */
+} PtrImage;
+
+/* LightMap of scene.cpp:76-80 after BuildSpectrumMipMap (texture.cpp:217-260) and
+ * CreateDistribution2D (infinite.cpp:24-39).  Only pyramid level 0 is reachable at
+ * render time (MipMap::Lookup with width 0, texture.h:168-171). */
+typedef struct {
+    PtrTransform light_to_world;
+    int32_t width, height; /* level-0 resolution (powers of two) */
+    int32_t nu, nv;        /* distribution resolution (2*width, 2*height) */
+    const float *texels;   /* 3*width*height, already multiplied by the scale */
+    const float *func;     /* nv*nu              Distribution1D::func of each row      */
+    const float *cdf;      /* nv*(nu+1)          Distribution1D::cdf  of each row      */
+    const float *func_int; /* nv                 funcInt of each row (= marginal func) */
+    const float *marg_cdf; /* nv+1                                                     */
+    float marg_int;
+    int32_t _pad;
+} PtrEnvMap;
+
+typedef struct {
+    int32_t n_primitives, n_meshes, n_clouds, n_images;
+    const PtrPrimitive *primitives; /* insertion order == hPrimitives, scene.cpp:70 */
+    const PtrMesh *meshes;
+    const PtrCloud *clouds;
+    const PtrImage *images;
+    PtrMedium camera_medium; /* is_valid = 0 when absent; InsertCameraMedium scene.cpp:721 */
+    int32_t has_envmap;
+    int32_t _pad;
+    PtrEnvMap envmap; /* InsertEXRLightMap scene.cpp:703 */
+} PtrFlatScene;
+
+/* Camera fields, src/core/camera.h:49-57 (medium comes from the scene, main.cpp:428) */
+typedef struct {
+    float position[3];
+    float lower_left[3];
+    float horizontal[3];
+    float vertical[3];
+    float lens_radius;
+    float u[3], v[3], w[3];
+} PtrCamera;
+
+/* Ray / hit counters: the reference's PixelStats (camera.h:12-21) summed over the
+ * image as ImageStats does (camera.cpp:86-125), plus ray counts the reference does
+ * not keep (every Aggregator::Intersect call equivalent). */
+typedef struct {
+    uint64_t total_paths;    /* extension rays = PixelStats::totalPaths, main.cpp:119,264 */
+    uint64_t misses;         /* PixelStats::misses                                        */
+    uint64_t surface_hits;   /* PixelStats::hits                                          */
+    uint64_t medium_hits;    /* PixelStats::mediumHits                                    */
+    uint64_t light_hits;     /* PixelStats::lightHits                                     */
+    uint64_t zero_radiance;  /* PixelStats::zeroRadiancePaths                             */
+    uint64_t shadow_rays;    /* scene queries issued by VisibilityTester (light.cpp:5-40) */
+    uint64_t mis_rays;       /* scene queries issued by the BSDF-sampling half of
+                                EstimateDirect (primitive.cpp:323-325, 433-461)           */
+    uint64_t probe_rays;     /* BSSRDF probe segments (bssrdf.cpp:536-553)                */
+    uint64_t camera_rays;    /* pixel-samples started                                     */
+    uint64_t nodes_visited;  /* child boxes tested by trace kernels (profiling builds)    */
+    uint64_t prims_tested;   /* leaf items tested by trace kernels (profiling builds)     */
+} PtrCounters;
+
+/* One entry per kernel family; filled by ptr_profile_read when profiling is on. */
+#define PTR_PROF_KERNELS 8
+typedef struct {
+    char name[32];
+    uint64_t launches;
+    double total_ms;
+    uint64_t items; /* rays / paths processed */
+} PtrKernelProfile;
+
+typedef struct PtrContext PtrContext;
+
+/* ---- lifetime ------------------------------------------------------------------- */
+
+/* Replaces cudaInitEx()/cudaInit() (src/cuda/cutil.cpp:80-139): pick the device, create
+ * the context.  device < 0 picks the current device. */
+int ptr_create(int device, PtrContext **out);
+/* Replaces ReleaseScene<<<1,1>>> + cudaFree of scene/camera (main.cpp:1150-1155). */
+int ptr_destroy(PtrContext *ctx);
+/* Replaces the print-and-exit error path of cutil.cpp:9-16,202-205: returns the text of
+ * the last failure on this thread ("" if none). */
+const char *ptr_last_error(void);
+/* Use a caller-owned hipStream_t for every launch of this context (default: the null
+ * stream).  No counterpart in the reference (single default stream). */
+int ptr_set_stream(PtrContext *ctx, void *hip_stream);
+
+/* ---- scene ---------------------------------------------------------------------- */
+
+/* Replaces PrepareSceneForRendering (scene.cpp:960-987): MakeSceneGPU<<<1,1>>>
+ * (scene.cpp:891), Aggregator::Wrap incl. MeshGetBounds / ParticleCloudGetBounds /
+ * BuildSceneTable kernels and the three CreateBVH calls (primitive.cpp:620-642,
+ * mesh.cpp:643-671, particlecloud.cpp:310-337) and MakeLights<<<1,1>>> (scene.cpp:948).
+ * Flattens, builds the compact BVH on the host, uploads. */
+int ptr_scene_upload(PtrContext *ctx, const PtrFlatScene *scene);
+/* Replaces Camera::Config's writes into the managed Camera (camera.cpp:145-197). */
+int ptr_camera_set(PtrContext *ctx, const PtrCamera *cam);
+
+/* ---- film ----------------------------------------------------------------------- */
+
+/* Replaces CreateImage + SetupPixels<<<blocks,threads>>>(image, seed) (camera.cpp:134,
+ * main.cpp:38-53,1110): zero accumulators, key the per-pixel RNG streams. */
+int ptr_film_init(PtrContext *ctx, int width, int height, uint64_t seed);
+/* Multi-GPU sharding (no counterpart; the reference is single-device): this context
+ * renders only sample indices s with s % stride == offset.  Default (0,1). */
+int ptr_film_shard(PtrContext *ctx, int sample_offset, int sample_stride);
+/* Replaces Render<<<blocks,threads>>>(image, scene, camera, ns) (main.cpp:421-457,1139):
+ * ns more samples for every pixel with integrator PTR_LI_*.  Asynchronous on the
+ * context's stream. */
+int ptr_render(PtrContext *ctx, int ns, int integrator);
+/* Replaces cudaDeviceAssert() after a launch (main.cpp:1140). */
+int ptr_sync(PtrContext *ctx);
+/* Replaces the host's reads of the managed Pixel array (GetPixelRGB camera.cpp:36-51,
+ * graphy.cpp:71-93): copies Pixel::we (3 floats/pixel), Pixel::accWeight, Pixel::samples
+ * to host arrays (any may be NULL).  Synchronises. */
+int ptr_film_read(PtrContext *ctx, float *we_rgb, double *acc_weight, int64_t *samples);
+/* Device addresses of the accumulators, for an RCCL reduce across ranks (no counterpart). */
+int ptr_film_device_ptrs(PtrContext *ctx, void **we_rgb, void **acc_weight, void **samples);
+/* Replaces ImageStats (camera.cpp:86-125). Synchronises. */
+int ptr_counters_read(PtrContext *ctx, PtrCounters *out);
+int ptr_counters_reset(PtrContext *ctx);
+
+/* ---- hot-path stages exposed for parity tests and benchmarks ------------------------ */
+
+/* Ray generation half of Render (main.cpp:436-443 + Camera::SpawnRay camera.cpp:219-224)
+ * for sample index `sample` of every pixel.  Device pointers, n = width*height entries:
+ * o[3n] d[3n] as SoA planes (x plane, y plane, z plane), weight[n] = GetFilterWeight. */
+int ptr_generate_rays(PtrContext *ctx, int sample, float *d_o, float *d_d, float *d_weight);
+/* Aggregator::Intersect (primitive.cpp:374-431) over a batch of n rays resident in HBM.
+ * SoA planes: d_o[3n], d_d[3n], d_tmax[n].  Outputs (device): prim[n] (-1 = miss),
+ * face[n] (triangle / particle / sdf shape id), t[n], b0[n], b1[n]. */
+int ptr_trace_closest(PtrContext *ctx, int n, const float *d_o, const float *d_d,
+                      const float *d_tmax, int32_t *d_prim, int32_t *d_face, float *d_t,
+                      float *d_b0, float *d_b1);
+/* VisibilityTester::Unoccluded (light.cpp:5-8): d_occluded[n] = 1 if anything is hit. */
+int ptr_trace_occluded(PtrContext *ctx, int n, const float *d_o, const float *d_d,
+                       const float *d_tmax, int32_t *d_occluded);
+
+/* ---- introspection (no counterpart) ----------------------------------------------- */
+int ptr_profile_enable(PtrContext *ctx, int on);
+int ptr_profile_reset(PtrContext *ctx);
+int ptr_profile_read(PtrContext *ctx, PtrKernelProfile *out, int max_entries, int *n_out);
+/* nodes, leaf items, bytes of the shipped BVH */
+int ptr_bvh_info(PtrContext *ctx, int64_t *n_nodes, int64_t *n_items, int64_t *bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTR_API_H */
