@@ -1,0 +1,554 @@
+/*
+ * dev_isect.h — ray/shape intersection and BVH traversal on gfx950.
+ *
+ * Two halves per shape, split the way a wavefront pipeline wants them:
+ *   *_hit_t   : what the trace kernels need — accept/reject and the hit parameter
+ *               (reference: the first half of each Shape::Intersect)
+ *   make_si   : what the shade kernel needs — the SurfaceInteraction rebuilt from
+ *               (ray, primitive, face, t), i.e. the second half of the same functions.
+ * Both halves perform the reference's arithmetic (citations inline), so t, barycentrics, hit
+ * point, normal and dpdu agree bit-for-bit with a host build up to the first libm call.
+ */
+#pragma once
+#include "dev_math.h"
+#include "dev_scene.h"
+
+struct SI { /* the fields of SurfaceInteraction the hot path reads (interaction.h:9-75) */
+    f3 p, pError, wo, n, dpdu;
+    f2 uv;
+    int prim, face;
+    int med_in, med_out;
+};
+
+/* geometry.h:1481-1499 with 1/d hoisted (the reference recomputes it per test; same values) */
+PD bool slab_test(const float *bmin, const float *bmax, const f3 &o, const f3 &inv, float tmax, float *t_entry, float *t_exit = nullptr) {
+    float t0 = 0, t1 = tmax;
+    const float k = 1 + 2 * gammar(3);
+    {
+        float tn = (bmin[0] - o.x) * inv.x, tf = (bmax[0] - o.x) * inv.x;
+        if (tn > tf) { float s = tn; tn = tf; tf = s; }
+        tf *= k;
+        t0 = tn > t0 ? tn : t0;
+        t1 = tf < t1 ? tf : t1;
+        if (t0 > t1) return false;
+    }
+    {
+        float tn = (bmin[1] - o.y) * inv.y, tf = (bmax[1] - o.y) * inv.y;
+        if (tn > tf) { float s = tn; tn = tf; tf = s; }
+        tf *= k;
+        t0 = tn > t0 ? tn : t0;
+        t1 = tf < t1 ? tf : t1;
+        if (t0 > t1) return false;
+    }
+    {
+        float tn = (bmin[2] - o.z) * inv.z, tf = (bmax[2] - o.z) * inv.z;
+        if (tn > tf) { float s = tn; tn = tf; tf = s; }
+        tf *= k;
+        t0 = tn > t0 ? tn : t0;
+        t1 = tf < t1 ? tf : t1;
+        if (t0 > t1) return false;
+    }
+    *t_entry = t0;
+    if (t_exit) *t_exit = t1;
+    return true;
+}
+
+/* ---- triangle, mesh.cpp:162-249 (watertight test, double fallback for zero edge functions) ---- */
+PD bool tri_hit(const f3 &ro, const f3 &rd, float tmax, const f3 &p0, const f3 &p1, const f3 &p2, float *tHit, float *ob0,
+                float *ob1, float *ob2) {
+    f3 p0t = p0 - ro, p1t = p1 - ro, p2t = p2 - ro;
+    int kz = max_dim(abs3(rd));
+    int kx = kz + 1; if (kx == 3) kx = 0;
+    int ky = kx + 1; if (ky == 3) ky = 0;
+    f3 d(comp(rd, kx), comp(rd, ky), comp(rd, kz));
+    p0t = f3(comp(p0t, kx), comp(p0t, ky), comp(p0t, kz));
+    p1t = f3(comp(p1t, kx), comp(p1t, ky), comp(p1t, kz));
+    p2t = f3(comp(p2t, kx), comp(p2t, ky), comp(p2t, kz));
+    float Sx = -d.x / d.z, Sy = -d.y / d.z, Sz = 1.f / d.z;
+    p0t.x += Sx * p0t.z; p0t.y += Sy * p0t.z;
+    p1t.x += Sx * p1t.z; p1t.y += Sy * p1t.z;
+    p2t.x += Sx * p2t.z; p2t.y += Sy * p2t.z;
+    float e0 = p1t.x * p2t.y - p1t.y * p2t.x;
+    float e1 = p2t.x * p0t.y - p2t.y * p0t.x;
+    float e2 = p0t.x * p1t.y - p0t.y * p1t.x;
+    if (is_zero(e0) || is_zero(e1) || is_zero(e2)) {
+        double p2txp1ty = (double)p2t.x * (double)p1t.y, p2typ1tx = (double)p2t.y * (double)p1t.x;
+        e0 = (float)(p2typ1tx - p2txp1ty);
+        double p0txp2ty = (double)p0t.x * (double)p2t.y, p0typ2tx = (double)p0t.y * (double)p2t.x;
+        e1 = (float)(p0typ2tx - p0txp2ty);
+        double p1txp0ty = (double)p1t.x * (double)p0t.y, p1typ0tx = (double)p1t.y * (double)p0t.x;
+        e2 = (float)(p1typ0tx - p1txp0ty);
+    }
+    if ((e0 < 0 || e1 < 0 || e2 < 0) && (e0 > 0 || e1 > 0 || e2 > 0)) return false;
+    float det = e0 + e1 + e2;
+    if (is_zero(det)) return false;
+    p0t.z *= Sz; p1t.z *= Sz; p2t.z *= Sz;
+    float tScaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
+    if (det < 0 && (tScaled >= 0 || tScaled < tmax * det)) return false;
+    else if (det > 0 && (tScaled <= 0 || tScaled > tmax * det)) return false;
+    float invDet = 1 / det;
+    float b0 = e0 * invDet, b1 = e1 * invDet, b2 = e2 * invDet;
+    float t = tScaled * invDet;
+    float maxZt = max_comp(abs3(f3(p0t.z, p1t.z, p2t.z)));
+    float deltaZ = gammar(3) * maxZt;
+    float maxXt = max_comp(abs3(f3(p0t.x, p1t.x, p2t.x)));
+    float maxYt = max_comp(abs3(f3(p0t.y, p1t.y, p2t.y)));
+    float deltaX = gammar(5) * (maxXt + maxZt);
+    float deltaY = gammar(5) * (maxYt + maxZt);
+    float deltaE = 2 * (gammar(2) * maxXt * maxYt + deltaY * maxXt + deltaX * maxYt);
+    float maxE = max_comp(abs3(f3(e0, e1, e2)));
+    float deltaT = 3 * (gammar(3) * maxE * maxZt + deltaE * maxZt + deltaZ * maxE) * absr(invDet);
+    if (t <= deltaT) return false;
+    *tHit = t;
+    *ob0 = b0; *ob1 = b1; *ob2 = b2;
+    return true;
+}
+
+/* ---- sphere, sphere.cpp:105-127.  Object-space ray given.  Every sphere the scene API can make
+ * is a full sphere (shape.h:74-78), for which the clipping branch of sphere.cpp:136-150 is never
+ * taken, so only t selection is needed here. */
+PD bool sphere_hit_t_obj(const f3 &o, const f3 &d, float radius, float tmax, float *tHit) {
+    float a = d.x * d.x + d.y * d.y + d.z * d.z;
+    float b = 2 * (d.x * o.x + d.y * o.y + d.z * o.z);
+    float c = o.x * o.x + o.y * o.y + o.z * o.z - radius * radius;
+    float t0, t1;
+    if (!quadratic(a, b, c, &t0, &t1)) return false;
+    if (t0 > tmax || t1 <= 0) return false;
+    float ts = t0;
+    if (ts <= 0 || is_unsafe_hit(ts)) {
+        ts = t1;
+        if (ts > tmax) return false;
+    }
+    *tHit = ts;
+    return true;
+}
+/* particle: toObject = Inverse(Translate(c)) (particlecloud.cpp:113-115).  With a pure
+ * translation xf_point_err reduces exactly to o - c with error gamma(3)*(|o|+|c|) and the
+ * direction is unchanged, so no matrices are built. */
+PD void particle_object_ray(const f3 &ro, const f3 &rd, const f3 &c, f3 *o, f3 *d) {
+    f3 oo = ro - c; /* (1*x + 0*y) + (0*z + (-c)) */
+    f3 oErr = gammar(3) * f3(absr(ro.x) + absr(-c.x), absr(ro.y) + absr(-c.y), absr(ro.z) + absr(-c.z));
+    float l2 = length2(rd);
+    if (l2 > 0) {
+        float dt = dot(abs3(rd), oErr) / l2;
+        oo += rd * dt;
+    }
+    *o = oo;
+    *d = rd;
+}
+
+/* ---- rectangle, rectangle.cpp:3-21 ---- */
+PD bool rect_hit_t(const DPrim &pr, const f3 &ro, const f3 &rd, float tmax, float *tHit) {
+    f3 o, d;
+    xf_ray_err(pr.w2o, ro, rd, &o, &d);
+    float hx = pr.p[0] / 2, hy = pr.p[1] / 2;
+    float zb = kShadowEpsilon * fmaxr(hx, hy);
+    float bmin[3] = {-hx, -hy, -zb}, bmax[3] = {hx, hy, zb};
+    f3 inv(1 / d.x, 1 / d.y, 1 / d.z);
+    float tmin;
+    if (!slab_test(bmin, bmax, o, inv, tmax, &tmin)) return false;
+    if (is_unsafe_hit(tmin)) return false;
+    f3 pHit = o + d * tmin;
+    if (pHit.x < -hx || pHit.x > hx || pHit.y < -hy || pHit.y > hy) return false;
+    *tHit = tmin;
+    return true;
+}
+/* ---- disk, disk.cpp:8-25 ---- */
+PD bool disk_hit_t(const DPrim &pr, const f3 &ro, const f3 &rd, float tmax, float *tHit) {
+    f3 o, d;
+    xf_ray_err(pr.w2o, ro, rd, &o, &d);
+    float height = pr.p[0], radius = pr.p[1], inner = pr.p[2], phiMax = pr.p[3];
+    if (is_zero(d.z)) return false;
+    float ts = (height - o.z) / d.z;
+    if (ts <= 0 || ts >= tmax) return false;
+    f3 pHit = o + d * ts;
+    float dist2v = pHit.x * pHit.x + pHit.y * pHit.y;
+    if (dist2v > radius * radius || dist2v < inner * inner) return false;
+    float phi = atan2f(pHit.y, pHit.x);
+    if (phi < 0) phi += 2 * kPi;
+    if (phi > phiMax) return false;
+    *tHit = ts;
+    return true;
+}
+
+/* ---- procedural (SDF) shapes, procedural.cpp ---- */
+PD float sdf_box(const f3 &p, const f3 &b) { /* :78-81 */
+    f3 d = abs3(p) - b;
+    return fminr(fmaxr(d.x, fmaxr(d.y, d.z)), 0.0f) + length(f3(fmaxr(d.x, 0.f), fmaxr(d.y, 0.f), fmaxr(d.z, 0.f)));
+}
+PD float proc_map(const DPrim &pr, const f3 &p, int *shapeId) {
+    if (pr.type == SH_SPHERE_PROC) return length(p) - pr.p[0];
+    if (pr.type == SH_BOX_PROC) return sdf_box(p, f3(pr.p[0], pr.p[1], pr.p[2]) * 0.5f);
+    /* SH_TOY id 4 "Terrain" (procedural.cpp:380-400): box over the component's extents */
+    f3 len(absr(pr.p[3] - pr.p[0]), absr(pr.p[4] - pr.p[1]), absr(pr.p[5] - pr.p[2]));
+    (void)shapeId;
+    return sdf_box(p, len * 0.5f);
+}
+PD void proc_local_bounds(const DPrim &pr, float *bmin, float *bmax) {
+    if (pr.type == SH_SPHERE_PROC) {
+        float r = pr.p[0];
+        bmin[0] = bmin[1] = bmin[2] = -r; bmax[0] = bmax[1] = bmax[2] = r;
+    } else if (pr.type == SH_BOX_PROC) {
+        f3 h = f3(pr.p[0], pr.p[1], pr.p[2]) * 0.5f;
+        bmin[0] = -h.x; bmin[1] = -h.y; bmin[2] = -h.z; bmax[0] = h.x; bmax[1] = h.y; bmax[2] = h.z;
+    } else {
+        for (int i = 0; i < 3; i++) { bmin[i] = pr.p[i]; bmax[i] = pr.p[3 + i]; }
+    }
+}
+PD bool inside_box(const f3 &p, const float *bmin, const float *bmax) {
+    return p.x >= bmin[0] && p.x <= bmax[0] && p.y >= bmin[1] && p.y <= bmax[1] && p.z >= bmin[2] && p.z <= bmax[2];
+}
+/* :187-227.  tHit is the distance along the NORMALISED direction (sic, :246). */
+PD bool proc_hit_t(const DPrim &pr, const f3 &ro, const f3 &rd, float rtmax, float *tHit, int *shapeId) {
+    f3 un = normalize(rd);
+    f3 o, d;
+    xf_ray_err(pr.w2o, ro, un, &o, &d);
+    float tMax = rtmax * length(rd);
+    float bmin[3], bmax[3];
+    proc_local_bounds(pr, bmin, bmax);
+    float t = 0;
+    if (!inside_box(o, bmin, bmax)) {
+        f3 inv(1 / d.x, 1 / d.y, 1 / d.z);
+        float t1, t2;
+        if (!slab_test(bmin, bmax, o, inv, kInfinity, &t1, &t2)) return false;
+        t = fminr(t1, t2);
+    }
+    int id = 0;
+    bool hit = false;
+    for (int i = 0; i < 256 && t < tMax; i++) {
+        f3 p = o + d * t;
+        float dd = proc_map(pr, p, &id);
+        if ((double)absr(dd) < (0.001 * t)) { hit = true; break; }
+        t += dd;
+        if (!inside_box(o + d * t, bmin, bmax)) break;
+    }
+    if (hit) { *tHit = t; *shapeId = id; }
+    return hit;
+}
+
+/* per-primitive dispatch used at PRIM leaves: reference leaf-node box test (the leaf's box is the
+ * primitive's own GetBounds(), primitive.cpp:386-390,557-563) followed by Shape::Intersect */
+PD bool prim_hit_t(const DScene &sc, int prim, const f3 &ro, const f3 &rd, const f3 &inv, float tmax, float *tHit, int *face) {
+    const DPrim &pr = sc.prims[prim];
+    float te;
+    if (!slab_test(pr.bmin, pr.bmax, ro, inv, tmax, &te)) return false;
+    *face = 0;
+    switch (pr.type) {
+    case SH_SPHERE: {
+        f3 o, d;
+        xf_ray_err(pr.w2o, ro, rd, &o, &d);
+        return sphere_hit_t_obj(o, d, pr.p[0], tmax, tHit);
+    }
+    case SH_RECT: return rect_hit_t(pr, ro, rd, tmax, tHit);
+    case SH_DISK: return disk_hit_t(pr, ro, rd, tmax, tHit);
+    case SH_SPHERE_PROC: case SH_BOX_PROC: case SH_TOY: return proc_hit_t(pr, ro, rd, tmax, tHit, face);
+    default: return false;
+    }
+}
+
+/* ---- BVH traversal (replaces primitive.cpp:374-431 + the nested loops of mesh.cpp:454-509 and
+ * particlecloud.cpp:197-274 with ONE loop over a unified, SAH-built, 64-byte-node BVH) ---------
+ * Closest hit: the reference accepts t <= tMax, so later equal-t candidates replace earlier ones;
+ * which one is "later" depends on its BVH — ties are reported by the oracle and excluded from
+ * exact comparison.  ANY = true returns at the first hit. */
+struct TraceStats { unsigned nodes, items; };
+
+template <bool ANY, bool COUNT>
+PD bool traverse(const DScene &sc, const f3 &ro, const f3 &rd, float &tmax, int &hprim, int &hface, float &hb0, float &hb1,
+                 TraceStats *st) {
+    int stack[BVH_STACK];
+    int sp = 0;
+    f3 inv(1 / rd.x, 1 / rd.y, 1 / rd.z);
+    bool hit = false;
+    int node = 0;
+    if (sc.n_nodes == 0) return false;
+    while (true) {
+        if (node >= 0) {
+            const float4 *np = reinterpret_cast<const float4 *>(sc.nodes + node);
+            float4 a = np[0], b = np[1], c = np[2], d = np[3];
+            float lmin[3] = {a.x, a.y, a.z}, lmax[3] = {a.w, b.x, b.y};
+            float rmin[3] = {b.z, b.w, c.x}, rmax[3] = {c.y, c.z, c.w};
+            int left = __float_as_int(d.x), right = __float_as_int(d.y);
+            float tl, tr;
+            bool hl = (left != BVH_NO_CHILD) && slab_test(lmin, lmax, ro, inv, tmax, &tl);
+            bool hr = (right != BVH_NO_CHILD) && slab_test(rmin, rmax, ro, inv, tmax, &tr);
+            if (COUNT) st->nodes += 2;
+            if (hl && hr) {
+                int first = left, second = right;
+                if (tr < tl) { first = right; second = left; }
+                if (sp < BVH_STACK) stack[sp++] = second;
+                node = first;
+                continue;
+            } else if (hl) { node = left; continue; }
+            else if (hr) { node = right; continue; }
+        } else {
+            unsigned packed = (unsigned)(-(node + 1));
+            unsigned first = packed & 0x07FFFFFFu, n = (packed >> 27) + 1;
+            for (unsigned i = 0; i < n; i++) {
+                const float4 *ip = reinterpret_cast<const float4 *>(sc.items + first + i);
+                float4 q0 = ip[0], q1 = ip[1], q2 = ip[2];
+                int kind = __float_as_int(q2.w);
+                int prim = __float_as_int(q0.w);
+                if (COUNT) st->items += 1;
+                if (kind == ITEM_TRI) {
+                    float t, b0, b1, b2;
+                    if (tri_hit(ro, rd, tmax, f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), &t, &b0, &b1, &b2)) {
+                        tmax = t; hprim = prim; hface = __float_as_int(q1.w); hb0 = b0; hb1 = b1; hit = true;
+                        if (ANY) return true;
+                    }
+                } else if (kind == ITEM_PARTICLE) {
+                    f3 o, d;
+                    particle_object_ray(ro, rd, f3(q0.x, q0.y, q0.z), &o, &d);
+                    float t;
+                    if (sphere_hit_t_obj(o, d, q1.x, tmax, &t)) {
+                        tmax = t; hprim = prim; hface = __float_as_int(q1.w); hb0 = 0; hb1 = 0; hit = true;
+                        if (ANY) return true;
+                    }
+                } else {
+                    float t;
+                    int face;
+                    if (prim_hit_t(sc, prim, ro, rd, inv, tmax, &t, &face)) {
+                        tmax = t; hprim = prim; hface = face; hb0 = 0; hb1 = 0; hit = true;
+                        if (ANY) return true;
+                    }
+                }
+            }
+        }
+        if (sp == 0) break;
+        node = stack[--sp];
+    }
+    return hit;
+}
+
+/* ---- SurfaceInteraction reconstruction ------------------------------------------------------- */
+/* SurfaceInteraction ctor (interaction.cpp:23-39) + Transform::operator()(SurfaceInteraction)
+ * (transform.cpp:224-256; note pError is NOT carried through the transform) for the
+ * object-space shapes. */
+PD void si_from_object(const DPrim &pr, const float *o2w, const float *w2o, const f3 &pHit, const f2 &uv, const f3 &wo_obj,
+                       const f3 &dpdu, const f3 &dpdv, int face, SI *si) {
+    f3 n = normalize(cross(dpdu, dpdv));
+    f3 wo = normalize(wo_obj);
+    if (pr.flags & PF_FLIP_N) n *= -1.0f;
+    si->p = xf_point(o2w, pHit);
+    si->n = normalize(xf_normal(w2o, n));
+    si->wo = normalize(xf_vec(o2w, wo));
+    si->pError = f3(0.f);
+    si->uv = uv;
+    si->dpdu = xf_vec(o2w, dpdu);
+    si->face = face;
+}
+
+/* sphere.cpp:129-190 / particlecloud.cpp:133-175 given the accepted t */
+PD void sphere_si(const DPrim &pr, const float *o2w, const float *w2o, const f3 &o, const f3 &d, float t, float radius, bool cloud,
+                  int face, SI *si) {
+    f3 pHit = o + d * t;
+    pHit *= radius / dist(pHit, f3(0, 0, 0));
+    if (pHit.x == 0 && pHit.y == 0) pHit.x = 1e-5f * radius;
+    float phi = atan2f(pHit.y, pHit.x);
+    if (phi < 0) phi += 2 * kPi;
+    float theta = acosf(clampr(pHit.z / radius, -1, 1));
+    float zRadius = sqrtf(pHit.x * pHit.x + pHit.y * pHit.y);
+    float invZRadius = 1 / zRadius;
+    float cosPhi = pHit.x * invZRadius, sinPhi = pHit.y * invZRadius;
+    float u, v;
+    f3 dpdu, dpdv;
+    if (!cloud) {
+        float thetaMin = pr.p[3], thetaMax = pr.p[4], phiMax = pr.p[5];
+        u = phi / phiMax;
+        v = (theta - thetaMin) / (thetaMax - thetaMin);
+        dpdu = f3(-phiMax * pHit.y, phiMax * pHit.x, 0);
+        dpdv = (thetaMax - thetaMin) * f3(pHit.z * cosPhi, pHit.z * sinPhi, -radius * sinf(theta));
+    } else {
+        float phiMax = 2 * kPi;
+        u = phi / (2 * kPi);
+        v = 1.0 - theta / kPi;
+        dpdu = f3(-phiMax * pHit.y, phiMax * pHit.x, 0);
+        dpdv = (float)(-kPi) * f3(pHit.z * cosPhi, pHit.z * sinPhi, -radius * sinf(theta));
+    }
+    si_from_object(pr, o2w, w2o, pHit, f2(u, v), -d, dpdu, dpdv, face, si);
+}
+
+/* procedural.cpp:145-185,228-247,263-352 */
+PD f3 proc_derivative_normal(const DPrim &pr, const f3 &p) {
+    bool found = false;
+    float scale = 0.001;
+    f3 n;
+    int it = 0, id;
+    while (!found) {
+        float e = scale * length(p);
+        float x = proc_map(pr, f3(p.x + e, p.y, p.z), &id) - proc_map(pr, f3(p.x - e, p.y, p.z), &id);
+        float y = proc_map(pr, f3(p.x, p.y + e, p.z), &id) - proc_map(pr, f3(p.x, p.y - e, p.z), &id);
+        float z = proc_map(pr, f3(p.x, p.y, p.z + e), &id) - proc_map(pr, f3(p.x, p.y, p.z - e), &id);
+        n = f3(x, y, z);
+        found = !is_zero(length(n));
+        if (!found) {
+            if (it++ > 10) { n = f3(0, 1, 0); break; }
+            scale *= 2;
+        }
+    }
+    return normalize(n);
+}
+PD void proc_si(const DPrim &pr, const f3 &ro, const f3 &rd, float t, int face, SI *si) {
+    f3 un = normalize(rd);
+    f3 o, d;
+    xf_ray_err(pr.w2o, ro, un, &o, &d);
+    f3 pHit = o + d * t;
+    f2 uv(0, 0);
+    f3 n;
+    bool refined = false;
+    if (pr.type == SH_SPHERE_PROC) {
+        float radius = pr.p[0];
+        face = 0;
+        pHit *= radius / dist(pHit, f3(0, 0, 0));
+        float phi = atan2f(pHit.y, pHit.x);
+        if (phi < 0) phi += 2 * kPi;
+        float u = phi / (2 * kPi);
+        float theta = acosf(clampr(pHit.z / radius, -1, 1));
+        float v = (kPi - theta) / kPi;
+        uv = f2(u, v);
+        n = f3(pHit.x, pHit.y, pHit.z) / radius;
+        refined = true;
+    } else if (pr.type == SH_BOX_PROC) {
+        f3 len(pr.p[0], pr.p[1], pr.p[2]);
+        f3 half = len * 0.5f;
+        float cx = kInfinity, cy = -1, cz = -1;
+        float q[6][3] = {{absr(pHit.x - half.x), 1, +half.x}, {absr(pHit.x + half.x), 3, -half.x}, {absr(pHit.y - half.y), 4, +half.y},
+                         {absr(pHit.y + half.y), 5, -half.y}, {absr(pHit.z - half.z), 2, +half.z}, {absr(pHit.z + half.z), 0, -half.z}};
+        for (int i = 0; i < 6; i++)
+            if (cx > q[i][0]) { cx = q[i][0]; cy = q[i][1]; cz = q[i][2]; }
+        int target = (int)cy;
+        float u = 0, v = 0;
+        if (target == 1 || target == 3) {
+            pHit.x = cz;
+            n = cz > 0 ? f3(1, 0, 0) : f3(-1, 0, 0);
+            u = (pHit.z + half.z) / len.z;
+            v = 1.f - (pHit.y + half.y) / len.y;
+        } else if (target == 4 || target == 5) {
+            pHit.y = cz;
+            n = cz > 0 ? f3(0, 1, 0) : f3(0, -1, 0);
+            u = (pHit.x + half.x) / len.x;
+            v = (pHit.z + half.z) / len.z;
+        } else {
+            pHit.z = cz;
+            n = cz > 0 ? f3(0, 0, 1) : f3(0, 0, -1);
+            u = (pHit.x + half.x) / len.x;
+            v = 1.f - (pHit.y + half.y) / len.z; /* sic */
+        }
+        uv = f2(u, v);
+        refined = true;
+    }
+    if (!refined) n = proc_derivative_normal(pr, pHit);
+    f3 dpdu, dpdv;
+    coordinate_system(n, &dpdu, &dpdv);
+    si_from_object(pr, pr.o2w, pr.w2o, pHit, uv, -d, dpdu, dpdv, face, si);
+}
+
+/* mesh.cpp:71-90 */
+PD void mesh_uvs(const DScene &sc, const DPrim &pr, int tri, f2 st[3]) {
+    const DMesh &m = sc.meshes[pr.geom];
+    st[0] = f2(0, 0); st[1] = f2(1, 0); st[2] = f2(1, 1);
+    if (m.uv) {
+        const int32_t *ix = sc.uvidx + 3 * (m.tri_base + tri);
+        int i0 = ix[0], i1 = ix[1], i2 = ix[2];
+        if (!((i0 < 0 || i0 > m.n_uvs) || (i1 < 0 || i1 > m.n_uvs) || (i2 < 0 || i2 > m.n_uvs))) {
+            st[0] = f2(m.uv[2 * i0], 1.0 - m.uv[2 * i0 + 1]);
+            st[1] = f2(m.uv[2 * i1], 1.0 - m.uv[2 * i1 + 1]);
+            st[2] = f2(m.uv[2 * i2], 1.0 - m.uv[2 * i2 + 1]);
+        }
+    }
+}
+PD void tri_vertices(const DScene &sc, const DPrim &pr, int tri, f3 *p0, f3 *p1, f3 *p2) {
+    const float *v = sc.tris + 9 * (sc.meshes[pr.geom].tri_base + tri);
+    *p0 = f3(v[0], v[1], v[2]); *p1 = f3(v[3], v[4], v[5]); *p2 = f3(v[6], v[7], v[8]);
+}
+/* mesh.cpp:251-303 */
+PD bool tri_si(const DScene &sc, const DPrim &pr, const f3 &ro, const f3 &rd, int tri, SI *si) {
+    f3 p0, p1, p2;
+    tri_vertices(sc, pr, tri, &p0, &p1, &p2);
+    float t, b0, b1, b2;
+    if (!tri_hit(ro, rd, kInfinity, p0, p1, p2, &t, &b0, &b1, &b2)) return false;
+    f2 st[3];
+    mesh_uvs(sc, pr, tri, st);
+    f2 dst02 = st[0] - st[2], dst12 = st[1] - st[2];
+    f3 dp02 = p0 - p2, dp12 = p1 - p2;
+    float determinant = dst02.x * dst12.y - dst02.y * dst12.x;
+    bool degenerateUV = (double)absr(determinant) < 1e-8;
+    if (degenerateUV) {
+        st[0] = f2(0, 0); st[1] = f2(1, 0); st[2] = f2(1, 1);
+        dst02 = st[0] - st[2]; dst12 = st[1] - st[2];
+        determinant = dst02.x * dst12.y - dst02.y * dst12.x;
+        degenerateUV = (double)absr(determinant) < 1e-8;
+    }
+    f3 dpdu;
+    if (!degenerateUV) {
+        float invdet = 1 / determinant;
+        dpdu = (dst12.y * dp02 - dst02.y * dp12) * invdet;
+    }
+    float xAbsSum = (absr(b0 * p0.x) + absr(b1 * p1.x) + absr(b2 * p2.x));
+    float yAbsSum = (absr(b0 * p0.y) + absr(b1 * p1.y) + absr(b2 * p2.y));
+    float zAbsSum = (absr(b0 * p0.z) + absr(b1 * p1.z) + absr(b2 * p2.z));
+    si->pError = gammar(7) * f3(xAbsSum, yAbsSum, zAbsSum);
+    si->p = b0 * p0 + b1 * p1 + b2 * p2;
+    si->uv = b0 * st[0] + b1 * st[1] + b2 * st[2];
+    si->wo = normalize(-rd);
+    si->dpdu = dpdu;
+    si->n = normalize(cross(dp02, dp12));
+    if (pr.flags & PF_FLIP_N) si->n = -si->n;
+    si->face = tri;
+    return true;
+}
+
+/* Rebuild the interaction of an accepted hit (prim, face, t) on ray (ro, rd); sets medium
+ * interface as PrimitiveIntersect does (primitive.cpp:66-71). */
+PD void make_si(const DScene &sc, int prim, int face, const f3 &ro, const f3 &rd, float t, int ray_medium, SI *si) {
+    const DPrim &pr = sc.prims[prim];
+    switch (pr.type) {
+    case SH_SPHERE: {
+        f3 o, d;
+        xf_ray_err(pr.w2o, ro, rd, &o, &d);
+        sphere_si(pr, pr.o2w, pr.w2o, o, d, t, pr.p[0], false, 0, si);
+    } break;
+    case SH_CLOUD: {
+        const DCloud &c = sc.clouds[pr.geom];
+        f3 ctr(c.pos[3 * face], c.pos[3 * face + 1], c.pos[3 * face + 2]);
+        f3 o, d;
+        particle_object_ray(ro, rd, ctr, &o, &d);
+        float o2w[12] = {1, 0, 0, ctr.x, 0, 1, 0, ctr.y, 0, 0, 1, ctr.z};
+        float w2o[12] = {1, 0, 0, -ctr.x, 0, 1, 0, -ctr.y, 0, 0, 1, -ctr.z};
+        sphere_si(pr, o2w, w2o, o, d, t, c.radius, true, face, si);
+    } break;
+    case SH_RECT: { /* rectangle.cpp:19-33 */
+        f3 o, d;
+        xf_ray_err(pr.w2o, ro, rd, &o, &d);
+        float hx = pr.p[0] / 2, hy = pr.p[1] / 2;
+        f3 pHit = o + d * t;
+        float u = absr((pHit.x - hx) / pr.p[0]);
+        float v = absr((pHit.y - hy) / pr.p[1]);
+        si_from_object(pr, pr.o2w, pr.w2o, pHit, f2(u, v), -d, f3(1, 0, 0), f3(0, 1, 0), 0, si);
+    } break;
+    case SH_DISK: { /* disk.cpp:18-40 */
+        f3 o, d;
+        xf_ray_err(pr.w2o, ro, rd, &o, &d);
+        float height = pr.p[0], radius = pr.p[1], inner = pr.p[2], phiMax = pr.p[3];
+        f3 pHit = o + d * t;
+        float dist2v = pHit.x * pHit.x + pHit.y * pHit.y;
+        float phi = atan2f(pHit.y, pHit.x);
+        if (phi < 0) phi += 2 * kPi;
+        float u = phi / phiMax;
+        float rHit = sqrtf(dist2v);
+        float v = (radius - rHit) / (radius - inner);
+        f3 dpdu(-phiMax * pHit.y, phiMax * pHit.x, 0);
+        f3 dpdv = f3(pHit.x, pHit.y, 0.) * (inner - radius) / rHit;
+        pHit.z = height;
+        si_from_object(pr, pr.o2w, pr.w2o, pHit, f2(u, v), -d, dpdu, dpdv, 0, si);
+    } break;
+    case SH_MESH: tri_si(sc, pr, ro, rd, face, si); break;
+    default: proc_si(pr, ro, rd, t, face, si); break;
+    }
+    si->prim = prim;
+    if (pr.med_inside != pr.med_outside) { si->med_in = pr.med_inside; si->med_out = pr.med_outside; }
+    else { si->med_in = ray_medium; si->med_out = ray_medium; }
+}
+
+/* Interaction::SpawnRay / SpawnRayTo, interaction.cpp:5-21 */
+PD int si_medium(const f3 &n, int med_in, int med_out, const f3 &w) { return dot(w, n) > 0 ? med_out : med_in; }

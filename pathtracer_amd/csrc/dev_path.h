@@ -1,0 +1,419 @@
+/*
+ * dev_path.h — per-vertex integrator logic of the wavefront pipeline.
+ * Reference: the Render kernel and its integrators (src/main.cpp:72-457), direct lighting
+ * (src/core/primitive.cpp:246-358), VisibilityTester (src/core/light.cpp:5-40) and
+ * Aggregator::IntersectTr (primitive.cpp:433-461).  The reference runs one thread per pixel
+ * through the whole path; here a path is a record in HBM that moves between three kernels per
+ * bounce (trace -> shade -> nee).  The arithmetic of one path is kept in the reference's order,
+ * including the order in which terms are added into L, so a path's radiance does not depend on
+ * how paths are scheduled.
+ */
+#pragma once
+#include "../../include/ptr_api.h"
+#include "dev_light.h"
+
+/* ---- counter-based RNG (DESIGN.md "RNG"; the reference's cuRAND state seeded with time(0),
+ * main.cpp:51,1102, is not reproducible by construction) ---- */
+PD uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+struct Rng {
+    uint64_t key;
+    uint32_t dim;
+    PD float next() {
+        uint64_t z = mix64(key + 0x9E3779B97F4A7C15ULL * ((uint64_t)dim + 1));
+        dim++;
+        uint32_t x = (uint32_t)(z >> 32);
+        float f = (float)x * 2.3283064365386963e-10f;
+        return f + 1.1641532182693481e-10f;
+    }
+};
+PD Rng make_rng(uint64_t seed, uint32_t pixel, uint32_t sample) {
+    Rng r;
+    uint64_t k = mix64(seed + 0x9E3779B97F4A7C15ULL * ((uint64_t)pixel + 1));
+    r.key = mix64(k ^ (0xD1B54A32D192ED03ULL * ((uint64_t)sample + 1)));
+    r.dim = 0;
+    return r;
+}
+/* Point2f(rand, rand) / Point3f(rand, rand, rand): g++ evaluates arguments right to left */
+PD f2 rand2(Rng &r) { float y = r.next(); float x = r.next(); return f2(x, y); }
+PD f3 rand3(Rng &r) { float z = r.next(); float y = r.next(); float x = r.next(); return f3(x, y, z); }
+
+/* ---- records in HBM ---- */
+enum { PFL_SPECULAR = 1 };
+struct __attribute__((aligned(16))) PathRec {
+    float L[3], beta[3];
+    int bounces, flags, dim, medium;
+    float weight;
+    int pad;
+};
+enum { NEE_A = 1, NEE_B = 2, NEE_MEDIUM = 4, NEE_COUNT_ZERO = 8 };
+struct __attribute__((aligned(16))) NeeRec {
+    float beta[3];
+    int flags;
+    /* light-sampling half: Ld += fA * LiA * wA / pdfA if the segment is unoccluded */
+    float fA[3], LiA[3], wA, pdfA;
+    float oA[3], dA[3];
+    int medA;
+    float p1[3], p1err[3], p1n[3];
+    /* BSDF / phase-sampling half: Ld += fB * Le(hit) * Tr * wB / pdfB */
+    float fB[3], wB, pdfB;
+    float oB[3], dB[3];
+    int medB, light;
+    int pad[2];
+};
+
+PD void st3(float *d, const f3 &v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; }
+PD f3 ld3(const float *s) { return f3(s[0], s[1], s[2]); }
+
+struct VertexCtr { unsigned total, miss, surf, med, light, zero; };
+
+/* Interaction::SpawnRayTo, interaction.cpp:11-21 */
+PD void spawn_ray_to(const f3 &p, const f3 &pErr, const f3 &n, int med_in, int med_out, const LightPoint &to, f3 *o, f3 *d, int *med) {
+    f3 origin = offset_ray_origin(p, pErr, n, to.p - p);
+    f3 target = offset_ray_origin(to.p, to.pError, to.n, origin - to.p);
+    *o = origin;
+    *d = target - origin;
+    *med = si_medium(n, med_in, med_out, *d);
+}
+
+/* EstimateDirect up to the two scene queries (primitive.cpp:246-339): everything that does not
+ * need a ray is evaluated here, the queries themselves are left to the nee kernel.
+ * Returns false if neither half has anything to trace. */
+PD bool build_nee(const DScene &sc, const Ref &it, const BSDF *bsdf, float phase_g, const f2 &u2, const f3 &u3, bool handleMedium,
+                  const f3 &beta, bool countZero, NeeRec *rec) {
+    int nLights = sc.n_lights;
+    int lightNum = (int)fminr((float)(int)(u2.x * nLights), (float)(nLights - 1));
+    f2 uLight(u2.y, u3.x);
+    f2 uScattering(u3.y, u3.z);
+    const DLight &light = sc.lights[lightNum];
+    const int bsdfFlags = BSDF_ALL & ~BSDF_SPECULAR;
+    int flags = 0;
+    f3 wi;
+    float lightPdf = 0, scatteringPdf = 0;
+    LightPoint p1;
+    f3 Li = light_sample_li(sc, light, it, uLight, &wi, &lightPdf, &p1);
+    if (lightPdf > 0 && !is_black(Li) && !is_zero(lightPdf)) {
+        f3 f;
+        if (bsdf) {
+            f = bsdf_f(*bsdf, it.wo, wi, bsdfFlags) * absdot(wi, it.n);
+            scatteringPdf = bsdf_pdf(*bsdf, it.wo, wi, bsdfFlags);
+        } else {
+            float p = phase_hg(dot(it.wo, wi), phase_g);
+            f = f3(p);
+            scatteringPdf = p;
+        }
+        if (!is_black(f)) {
+            flags |= NEE_A;
+            st3(rec->fA, f);
+            st3(rec->LiA, Li);
+            rec->wA = power_heuristic(1, lightPdf, 1, scatteringPdf);
+            rec->pdfA = lightPdf;
+            f3 o, d;
+            int med;
+            spawn_ray_to(it.p, it.pError, it.n, it.med_in, it.med_out, p1, &o, &d, &med);
+            st3(rec->oA, o);
+            st3(rec->dA, d);
+            rec->medA = med;
+            st3(rec->p1, p1.p);
+            st3(rec->p1err, p1.pError);
+            st3(rec->p1n, p1.n);
+        }
+    }
+    {
+        f3 f;
+        bool sampledSpecular = false;
+        if (bsdf) {
+            int sampledType = 0;
+            f = bsdf_sample_f(*bsdf, it.wo, &wi, uScattering, &scatteringPdf, bsdfFlags, &sampledType);
+            f *= absdot(wi, it.n);
+            sampledSpecular = (sampledType & BSDF_SPECULAR) != 0;
+        } else {
+            float p = phase_sample_p(phase_g, it.wo, &wi, uScattering);
+            f = f3(p);
+            scatteringPdf = p;
+        }
+        if (!is_black(f) && scatteringPdf > 0 && !is_zero(scatteringPdf)) {
+            float weight = 1;
+            bool ok = true;
+            if (!sampledSpecular) {
+                lightPdf = light_pdf_li(sc, light, it, wi);
+                if (is_zero(lightPdf)) ok = false;
+                else weight = power_heuristic(1, scatteringPdf, 1, lightPdf);
+            }
+            if (ok) {
+                flags |= NEE_B;
+                st3(rec->fB, f);
+                rec->wB = weight;
+                rec->pdfB = scatteringPdf;
+                st3(rec->oB, offset_ray_origin(it.p, it.pError, it.n, wi));
+                st3(rec->dB, wi);
+                rec->medB = ref_medium(it, wi);
+                rec->light = lightNum;
+            }
+        }
+    }
+    if (!(flags & (NEE_A | NEE_B))) return false;
+    if (handleMedium) flags |= NEE_MEDIUM;
+    if (countZero) flags |= NEE_COUNT_ZERO;
+    rec->flags = flags;
+    st3(rec->beta, beta);
+    return true;
+}
+
+/* What one vertex hands back to the kernel */
+struct VertexOut {
+    bool alive;    /* the path continues with the ray written to (ro, rd, medium) */
+    bool want_nee; /* *rec was filled */
+};
+
+/* One loop iteration of Li_Direct / Li_Path / Li_PathSampled / Li_VolPath (main.cpp:72-410).
+ * On entry (ro, rd) is the ray that was traced and (hp, hf, ht) its closest hit (hp < 0: miss). */
+PD VertexOut shade_vertex(const DScene &sc, int integrator, Rng &rng, f3 &ro, f3 &rd, int &ray_medium, int hp, int hf, float ht, f3 &L,
+                          f3 &beta, int &bounces, int &pflags, NeeRec *rec, VertexCtr &ctr) {
+    VertexOut out;
+    out.alive = false;
+    out.want_nee = false;
+    const bool found = hp >= 0;
+    SI si;
+    BSDF bsdf;
+    BssrdfParams bp;
+
+    if (integrator == PTR_LI_DIRECT) { /* main.cpp:72-98 */
+        ctr.total++;
+        if (!found) {
+            for (int i = 0; i < sc.n_lights; i++) L += light_le(sc, sc.lights[i], rd);
+            return out;
+        }
+        make_si(sc, hp, hf, ro, rd, ht, ray_medium, &si);
+        bsdf_init(&bsdf, si);
+        compute_scattering(sc, si, &bsdf, &bp);
+        L += surface_le(sc, hp);
+        if (sc.n_lights > 0) {
+            f2 u2 = rand2(rng);
+            f3 u3 = rand3(rng);
+            out.want_nee = build_nee(sc, ref_from_si(si), &bsdf, 0, u2, u3, false, f3(1.f), false, rec);
+        }
+        return out;
+    }
+
+    if (integrator == PTR_LI_PATH) { /* main.cpp:362-410 */
+        const int max_bounces = 10;
+        ctr.total++;
+        bool brk = true;
+        if (found) {
+            make_si(sc, hp, hf, ro, rd, ht, ray_medium, &si);
+            bsdf_init(&bsdf, si);
+            float pdf = 0.f;
+            f2 u = rand2(rng);
+            f3 wi, wo = -rd;
+            bool scatters = compute_scattering(sc, si, &bsdf, &bp);
+            const DPrim &pr = sc.prims[hp];
+            f3 Le = (pr.flags & PF_EMISSIVE) ? f3(pr.L[0], pr.L[1], pr.L[2]) : f3(0.f);
+            L += beta * Le;
+            int st = 0;
+            f3 f(0.f);
+            if (scatters) f = bsdf_sample_f(bsdf, wo, &wi, u, &pdf, BSDF_ALL, &st);
+            if (!is_zero(pdf)) {
+                beta *= f * absdot(wi, si.n) / pdf;
+                Ref it = ref_from_si(si);
+                ro = offset_ray_origin(it.p, it.pError, it.n, wi);
+                ray_medium = ref_medium(it, wi);
+                rd = wi;
+                ctr.surf++;
+                brk = false;
+                if (max_comp(beta) < 1.f && bounces > 3) {
+                    float q = fmaxr((float).05, 1 - max_comp(beta));
+                    float uu = rng.next();
+                    if (uu < q) brk = true;
+                    else beta = beta / (1 - q);
+                }
+            }
+        } else {
+            L = sum_lights_le(sc, rd, beta, L);
+            ctr.miss++;
+        }
+        if (brk) {
+            if (bounces == max_bounces - 1) L = f3(0.f); /* sic, main.cpp:408 */
+            return out;
+        }
+        bounces++;
+        out.alive = bounces < max_bounces;
+        return out;
+    }
+
+    /* Li_PathSampled (main.cpp:251-354) and Li_VolPath (main.cpp:105-243) */
+    const bool vol = integrator == PTR_LI_VOLPATH;
+    const int max_bounces = vol ? 15 : 10;
+    ctr.total++;
+    ctr.miss += !found ? 1 : 0;
+    bool scattered_in_medium = false;
+    if (vol) {
+        bool sampled = false;
+        f3 pm;
+        float g = 0;
+        if (ray_medium >= 0) {
+            f2 u = rand2(rng);
+            beta *= medium_sample(sc.media[ray_medium], ro, rd, found ? ht : kInfinity, u, &sampled, &pm, &g);
+        }
+        if (is_black(beta)) return out;
+        if (sampled) {
+            if (bounces >= max_bounces) return out;
+            Ref it;
+            it.p = pm; it.pError = f3(0.f); it.n = f3(0.f); it.wo = -rd; it.face = -1; it.med_in = ray_medium; it.med_out = ray_medium;
+            f2 u2 = rand2(rng);
+            f3 u3 = rand3(rng);
+            if (sc.n_lights < 1) ctr.zero++;
+            else out.want_nee = build_nee(sc, it, nullptr, g, u2, u3, true, beta, true, rec);
+            if (sc.n_lights >= 1 && !out.want_nee) ctr.zero++;
+            f3 wo = -rd, wi;
+            u2 = rand2(rng);
+            phase_sample_p(g, wo, &wi, u2);
+            ro = pm; /* OffsetRayOrigin with n = 0 leaves p unchanged */
+            rd = wi;
+            pflags &= ~PFL_SPECULAR;
+            ctr.med++;
+            scattered_in_medium = true;
+        }
+    }
+    if (!scattered_in_medium) {
+        if (bounces == 0 || (pflags & PFL_SPECULAR)) {
+            if (found) L += beta * surface_le(sc, hp);
+            else L = sum_lights_le(sc, rd, beta, L);
+        }
+        if (!found || bounces >= max_bounces) return out;
+        const DPrim &pr = sc.prims[hp];
+        if (pr.flags & PF_EMISSIVE) ctr.light++;
+        make_si(sc, hp, hf, ro, rd, ht, ray_medium, &si);
+        bsdf_init(&bsdf, si);
+        bool scatters = compute_scattering(sc, si, &bsdf, &bp);
+        if (!scatters) return out; /* emitter: its single lobe matches no flag, Sample_f returns pdf 0 */
+        Ref it = ref_from_si(si);
+        if (bsdf.n == 0) { /* medium boundary without material: pass through, bounce not counted */
+            ro = offset_ray_origin(it.p, it.pError, it.n, rd);
+            ray_medium = ref_medium(it, rd);
+            out.alive = true;
+            return out;
+        }
+        if (bsdf_num_components(bsdf, BSDF_ALL & ~BSDF_SPECULAR) > 0) {
+            f2 u2 = rand2(rng);
+            f3 u3 = rand3(rng);
+            if (sc.n_lights < 1) ctr.zero++;
+            else {
+                out.want_nee = build_nee(sc, it, &bsdf, 0, u2, u3, vol, beta, true, rec);
+                if (!out.want_nee) ctr.zero++;
+            }
+        }
+        float pdf = 0.f;
+        f2 u = rand2(rng);
+        f3 wi, wo = -rd;
+        int flags = 0;
+        f3 f = bsdf_sample_f(bsdf, wo, &wi, u, &pdf, BSDF_ALL, &flags);
+        if (is_black(f) || is_zero(pdf)) return out;
+        beta *= f * absdot(wi, si.n) / pdf;
+        if (flags & BSDF_SPECULAR) pflags |= PFL_SPECULAR;
+        else pflags &= ~PFL_SPECULAR;
+        ro = offset_ray_origin(it.p, it.pError, it.n, wi);
+        ray_medium = ref_medium(it, wi);
+        rd = wi;
+        ctr.surf++;
+    }
+    if (max_comp(beta) < 1.f && bounces > 3) {
+        float q = fmaxr((float).05, 1 - max_comp(beta));
+        float uu = rng.next();
+        if (uu < q) return out;
+        beta = beta / (1 - q);
+    }
+    bounces++;
+    out.alive = true;
+    return out;
+}
+
+/* ---- the two scene queries of EstimateDirect and the final sum (primitive.cpp:270-357) ---- */
+struct NeeCtr { unsigned shadow, mis, zero; };
+
+/* VisibilityTester::Tr, light.cpp:10-40 */
+PD f3 vis_tr(const DScene &sc, const NeeRec &rec, NeeCtr &ctr) {
+    f3 ro = ld3(rec.oA), rd = ld3(rec.dA);
+    int med = rec.medA;
+    LightPoint p1;
+    p1.p = ld3(rec.p1); p1.pError = ld3(rec.p1err); p1.n = ld3(rec.p1n);
+    f3 Tr(1.f);
+    for (int guard = 0; guard < 256; guard++) {
+        float tmax = 1 - kShadowEpsilon;
+        int hp = -1, hf = 0;
+        float b0, b1;
+        ctr.shadow++;
+        bool hit = traverse<false, false>(sc, ro, rd, tmax, hp, hf, b0, b1, nullptr);
+        if (hit && sc.prims[hp].material >= 0) return f3(0.0f);
+        if (med >= 0) Tr *= medium_tr(sc.media[med], rd, tmax);
+        if (!hit || (sc.prims[hp].flags & PF_EMISSIVE)) break;
+        SI si;
+        make_si(sc, hp, hf, ro, rd, tmax, med, &si);
+        spawn_ray_to(si.p, si.pError, si.n, si.med_in, si.med_out, p1, &ro, &rd, &med);
+    }
+    return Tr;
+}
+/* Aggregator::IntersectTr, primitive.cpp:433-461 */
+PD bool intersect_tr(const DScene &sc, f3 ro, const f3 &rd, int med, int *hprim, f3 *Tr, NeeCtr &ctr) {
+    *Tr = f3(1.f);
+    for (int guard = 0; guard < 256; guard++) {
+        float tmax = kInfinity;
+        int hp = -1, hf = 0;
+        float b0, b1;
+        ctr.mis++;
+        bool hit = traverse<false, false>(sc, ro, rd, tmax, hp, hf, b0, b1, nullptr);
+        if (med >= 0) *Tr *= medium_tr(sc.media[med], rd, tmax);
+        if (!hit || (sc.prims[hp].flags & PF_EMISSIVE)) return false;
+        if (sc.prims[hp].material >= 0) { *hprim = hp; return true; }
+        SI si;
+        make_si(sc, hp, hf, ro, rd, tmax, med, &si);
+        ro = offset_ray_origin(si.p, si.pError, si.n, rd);
+        med = si_medium(si.n, si.med_in, si.med_out, rd);
+    }
+    return false;
+}
+
+PD f3 resolve_nee(const DScene &sc, const NeeRec &rec, NeeCtr &ctr) {
+    f3 Ld(0.f);
+    const bool medium = (rec.flags & NEE_MEDIUM) != 0;
+    if (rec.flags & NEE_A) {
+        f3 Li = ld3(rec.LiA);
+        if (medium) Li *= vis_tr(sc, rec, ctr);
+        else {
+            float tmax = 1 - kShadowEpsilon;
+            int hp = -1, hf = 0;
+            float b0, b1;
+            ctr.shadow++;
+            if (traverse<true, false>(sc, ld3(rec.oA), ld3(rec.dA), tmax, hp, hf, b0, b1, nullptr)) Li = f3(0.f);
+        }
+        if (!is_black(Li)) Ld += ld3(rec.fA) * Li * rec.wA / rec.pdfA;
+    }
+    if (rec.flags & NEE_B) {
+        f3 Tr(1.f);
+        bool found;
+        int hp = -1;
+        f3 rd = ld3(rec.dB);
+        if (medium) found = intersect_tr(sc, ld3(rec.oB), rd, rec.medB, &hp, &Tr, ctr);
+        else {
+            float tmax = kInfinity;
+            int hf = 0;
+            float b0, b1;
+            ctr.mis++;
+            found = traverse<false, false>(sc, ld3(rec.oB), rd, tmax, hp, hf, b0, b1, nullptr);
+        }
+        f3 Li2(0.f);
+        if (found) {
+            if (sc.prims[hp].light == rec.light) Li2 = surface_le(sc, hp);
+        } else Li2 = light_le(sc, sc.lights[rec.light], rd);
+        if (!is_black(Li2)) Ld += ld3(rec.fB) * Li2 * Tr * rec.wB / rec.pdfB;
+    }
+    /* UniformSampleOneLight: / lightPdf with lightPdf = 1 / nLights, primitive.cpp:341-358 */
+    float selPdf = float(1) / sc.n_lights;
+    f3 uL = Ld / selPdf;
+    f3 out = ld3(rec.beta) * uL;
+    if ((rec.flags & NEE_COUNT_ZERO) && is_black(out)) ctr.zero++;
+    return out;
+}

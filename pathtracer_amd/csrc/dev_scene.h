@@ -1,0 +1,110 @@
+/*
+ * dev_scene.h — flat device-resident scene tables (what the reference keeps as a pointer-linked
+ * object graph in managed memory: Aggregator/Primitive/Shape/Material/Light, primitive.h:13-130).
+ * Shared by the host flattening code (ptr_scene.cpp) and the kernels.
+ */
+#pragma once
+#include <cstdint>
+
+enum { SH_SPHERE = 0, SH_RECT = 1, SH_DISK = 2, SH_BOX = 3, SH_MESH = 4, SH_CLOUD = 5, SH_SPHERE_PROC = 6, SH_BOX_PROC = 7, SH_TOY = 8 };
+enum { PF_FLIP_N = 1, PF_REVERSE = 2, PF_EMISSIVE = 4 };
+enum { ITEM_TRI = 0, ITEM_PARTICLE = 1, ITEM_PRIM = 2 };
+enum { LT_AREA = 1, LT_DISTANT = 2, LT_INFINITE = 3 };
+
+/* Compact BVH node, 64 B = one 64-byte line: both children's boxes + refs, so one fetch serves
+ * two slab tests.  ref >= 0: index of an inner node; ref < 0: leaf, -(ref+1) = first | (n-1)<<27;
+ * an absent child has n = 0 encoded as ref = INT32_MIN. */
+struct Node64 {
+    float lmin[3], lmax[3];
+    float rmin[3], rmax[3];
+    int32_t left, right;
+    int32_t pad[2];
+};
+#define BVH_NO_CHILD INT32_MIN
+#define BVH_MAX_LEAF 4
+#define BVH_STACK 64
+
+/* Leaf record, 48 B (3 x float4), pre-gathered so a leaf test needs no indirection:
+ *  TRI      : q0 = (p0, prim)  q1 = (p1, tri)       q2 = (p2, ITEM_TRI)
+ *  PARTICLE : q0 = (c,  prim)  q1 = (r,0,0, index)  q2 = (0,0,0, ITEM_PARTICLE)
+ *  PRIM     : q0 = (bmin,prim) q1 = (bmax, 0)       q2 = (0,0,0, ITEM_PRIM)   (ints stored bitwise) */
+struct Item48 {
+    float q[12];
+};
+
+struct DPrim {
+    int32_t type, flags, geom, material;
+    int32_t light, med_inside, med_outside, toy_id;
+    float o2w[12], w2o[12]; /* rows 0..2 of ObjectToWorld.m / WorldToObject.m */
+    float bmin[3], bmax[3]; /* Shape::GetBounds() in world space */
+    float p[8];             /* sphere: radius,zMin,zMax,thetaMin,thetaMax,phiMax | rect: sizex,sizey |
+                               disk: height,radius,innerRadius,phiMax | box: length xyz |
+                               toy: bounds pMin xyz, pMax xyz | cloud: radius */
+    float L[3];
+    float area; /* Shape::Area() (unused for meshes: their sampling works per triangle) */
+};
+
+struct DTex {
+    int32_t type; /* 0 spectrum, 1 float, 2 image */
+    float v[3];   /* spectrum, or (fval, -, -) */
+    int32_t image;
+};
+struct DMat {
+    int32_t type, ntex, id, table;
+    float vals[4];
+    DTex tex[16];
+};
+struct DMedium {
+    float sigma_a[3], sigma_s[3], sigma_t[3];
+    float g;
+};
+struct DLight {
+    int32_t type, prim;
+    float Lemit[3];
+    float l2w[12], w2l[12];
+    float worldRadius;
+};
+struct DImage {
+    const float *rgb;
+    int32_t width, height;
+};
+struct DMesh {
+    int64_t tri_base; /* into tris (9 floats each) and uvidx (3 ints each) */
+    int32_t n_tris, n_uvs;
+    const float *uv;  /* 2*n_uvs or null */
+};
+struct DCloud {
+    const float *pos; /* 3*n */
+    int32_t n;
+    float radius;
+};
+struct DTable { /* BSSRDFTable, bssrdf.h:29-42 (100 x 64) */
+    const float *rhoSamples, *radiusSamples, *profile, *rhoEff, *profileCDF;
+    int32_t nRho, nRadius;
+};
+
+struct DScene {
+    const Node64 *nodes;
+    const Item48 *items;
+    const DPrim *prims;
+    const DMat *mats;
+    const DMedium *media;
+    const DLight *lights;
+    const DImage *images;
+    const DMesh *meshes;
+    const DCloud *clouds;
+    const DTable *tables;
+    const float *tris;     /* 9 floats / triangle, original order, world space */
+    const int32_t *uvidx;  /* 3 ints / triangle */
+    /* environment map */
+    const float *env_texels, *env_func, *env_cdf, *env_func_int, *env_marg_cdf;
+    float env_marg_int;
+    int32_t env_w, env_h, env_nu, env_nv;
+    int32_t n_prims, n_lights, n_nodes, n_items;
+    int32_t view_medium, has_env;
+};
+
+struct DCamera {
+    float position[3], lower_left[3], horizontal[3], vertical[3], u[3], v[3], w[3];
+    float lens_radius;
+};

@@ -1,0 +1,537 @@
+/*
+ * ptr_build.cpp — flat scene -> device tables + unified SAH BVH (host side).
+ *
+ * What it replaces in the reference: MakeSceneGPU (scene.cpp:891-946: shapes, materials, media,
+ * primitives), Mesh ctor (mesh.cpp:28-69: vertices to world space), Aggregator::Wrap
+ * (primitive.cpp:620-642) with MeshGetBounds / ParticleCloudGetBounds / MakeSceneTable and the
+ * three CreateBVH median-split builds, Aggregator::Insert / MakeLights / SetLights
+ * (primitive.cpp:164-244, scene.cpp:948-958).
+ *
+ * Every derived scalar the render path later reads (sphere angles, world bounds, areas, the
+ * light-map world radius) is computed with the reference's own expressions in float, so the
+ * kernels start from bit-identical inputs; the acceleration structure itself is new.
+ */
+#include "ptr_host.h"
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+
+namespace {
+
+const double kPiD = 3.14159265358979323846;
+
+struct V3h { float x, y, z; };
+inline float radians_f(float deg) { return (float)((kPiD / 180) * deg); }
+inline float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* transform.h:135-148 on the full 4x4 (row 3 is checked to be 0,0,0,1 before) */
+inline V3h xf_point16(const float *m, V3h p) {
+    V3h r;
+    r.x = m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3];
+    r.y = m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7];
+    r.z = m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11];
+    return r;
+}
+struct Box {
+    float mn[3], mx[3];
+    void reset() { for (int i = 0; i < 3; i++) { mn[i] = FLT_MAX; mx[i] = -FLT_MAX; } }
+    void grow(const float *p) { for (int i = 0; i < 3; i++) { if (p[i] < mn[i]) mn[i] = p[i]; if (p[i] > mx[i]) mx[i] = p[i]; } }
+    void grow(const Box &b) { grow(b.mn); grow(b.mx); }
+    float half_area() const {
+        float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+        if (dx < 0 || dy < 0 || dz < 0) return 0;
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+/* Transform::operator()(Bounds3f), transform.h:250-265: union of the 8 corners */
+Box xf_bounds16(const float *m, const float *bmin, const float *bmax) {
+    Box b;
+    b.reset();
+    const float *c[2] = {bmin, bmax};
+    for (int k = 0; k < 8; k++) {
+        V3h p = {c[k & 1][0], c[(k >> 1) & 1][1], c[(k >> 2) & 1][2]};
+        V3h q = xf_point16(m, p);
+        float qq[3] = {q.x, q.y, q.z};
+        b.grow(qq);
+    }
+    return b;
+}
+bool is_affine(const float *m) { return m[12] == 0 && m[13] == 0 && m[14] == 0 && m[15] == 1; }
+bool swaps_handedness(const float *m) { /* transform.cpp:203-208 */
+    float det = m[0] * (m[5] * m[10] - m[6] * m[9]) - m[1] * (m[4] * m[10] - m[6] * m[8]) + m[2] * (m[4] * m[9] - m[5] * m[8]);
+    return det < 0;
+}
+void copy34(float *dst, const float *m16) { memcpy(dst, m16, 12 * sizeof(float)); }
+
+DMedium conv_medium(const PtrMedium &pm) {
+    DMedium m;
+    for (int i = 0; i < 3; i++) {
+        m.sigma_a[i] = pm.sigma_a[i];
+        m.sigma_s[i] = pm.sigma_s[i];
+        m.sigma_t[i] = pm.sigma_a[i] + pm.sigma_s[i];
+    }
+    m.g = pm.g;
+    return m;
+}
+
+inline float as_float(int32_t v) { float f; memcpy(&f, &v, 4); return f; }
+
+/* ---- binned SAH build ----------------------------------------------------------------- */
+struct Builder {
+    const std::vector<Box> &boxes;
+    std::vector<uint32_t> idx;
+    std::vector<float> cen; /* 3 per item */
+    std::vector<Node64> nodes;
+    std::vector<uint32_t> order;
+    int max_depth = 0;
+    static const int NB = 32;
+
+    explicit Builder(const std::vector<Box> &b) : boxes(b) {
+        idx.resize(b.size());
+        cen.resize(3 * b.size());
+        for (size_t i = 0; i < b.size(); i++) {
+            idx[i] = (uint32_t)i;
+            for (int a = 0; a < 3; a++) cen[3 * i + a] = 0.5f * (b[i].mn[a] + b[i].mx[a]);
+        }
+    }
+    int32_t make_leaf(size_t lo, size_t hi) {
+        uint32_t first = (uint32_t)order.size(), n = (uint32_t)(hi - lo);
+        for (size_t i = lo; i < hi; i++) order.push_back(idx[i]);
+        uint32_t packed = first | ((n - 1) << 27);
+        return -(int32_t)packed - 1;
+    }
+    /* returns the child ref for items [lo, hi) and their box */
+    int32_t build(size_t lo, size_t hi, Box *outBox, int depth) {
+        size_t n = hi - lo;
+        Box bb, cb;
+        bb.reset();
+        cb.reset();
+        for (size_t i = lo; i < hi; i++) {
+            bb.grow(boxes[idx[i]]);
+            cb.grow(&cen[3 * idx[i]]);
+        }
+        *outBox = bb;
+        if (depth > max_depth) max_depth = depth;
+        if (n <= 2) return make_leaf(lo, hi);
+
+        size_t mid = 0;
+        bool have_split = false;
+        float best_cost = FLT_MAX;
+        if (depth <= 28) {
+            int best_axis = -1, best_bin = -1;
+            for (int a = 0; a < 3; a++) {
+                float ext = cb.mx[a] - cb.mn[a];
+                if (!(ext > 0)) continue;
+                Box bin_box[NB];
+                uint32_t bin_n[NB];
+                for (int b = 0; b < NB; b++) { bin_box[b].reset(); bin_n[b] = 0; }
+                float scale = NB / ext;
+                for (size_t i = lo; i < hi; i++) {
+                    int b = (int)((cen[3 * idx[i] + a] - cb.mn[a]) * scale);
+                    if (b < 0) b = 0;
+                    if (b > NB - 1) b = NB - 1;
+                    bin_box[b].grow(boxes[idx[i]]);
+                    bin_n[b]++;
+                }
+                float right_area[NB];
+                uint32_t right_n[NB];
+                Box acc;
+                acc.reset();
+                uint32_t cnt = 0;
+                for (int b = NB - 1; b > 0; b--) {
+                    acc.grow(bin_box[b]);
+                    cnt += bin_n[b];
+                    right_area[b] = acc.half_area();
+                    right_n[b] = cnt;
+                }
+                acc.reset();
+                cnt = 0;
+                for (int b = 0; b < NB - 1; b++) {
+                    acc.grow(bin_box[b]);
+                    cnt += bin_n[b];
+                    if (cnt == 0 || right_n[b + 1] == 0) continue;
+                    float cost = acc.half_area() * cnt + right_area[b + 1] * right_n[b + 1];
+                    if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = b; }
+                }
+            }
+            if (best_axis >= 0) {
+                float parent = bb.half_area();
+                float split_cost = 1.0f + (parent > 0 ? best_cost / parent : (float)n);
+                if (n <= BVH_MAX_LEAF && (float)n <= split_cost) return make_leaf(lo, hi);
+                float ext = cb.mx[best_axis] - cb.mn[best_axis];
+                float scale = NB / ext;
+                float cmin = cb.mn[best_axis];
+                auto it = std::partition(idx.begin() + lo, idx.begin() + hi, [&](uint32_t id) {
+                    int b = (int)((cen[3 * id + best_axis] - cmin) * scale);
+                    if (b < 0) b = 0;
+                    if (b > NB - 1) b = NB - 1;
+                    return b <= best_bin;
+                });
+                mid = (size_t)(it - idx.begin());
+                have_split = mid > lo && mid < hi;
+            }
+        }
+        if (!have_split) {
+            if (n <= BVH_MAX_LEAF) return make_leaf(lo, hi);
+            /* coincident centroids or depth guard: split the index range in half on the widest axis */
+            int a = 0;
+            float e0 = cb.mx[0] - cb.mn[0], e1 = cb.mx[1] - cb.mn[1], e2 = cb.mx[2] - cb.mn[2];
+            if (e1 > e0 && e1 >= e2) a = 1;
+            else if (e2 > e0 && e2 > e1) a = 2;
+            mid = lo + n / 2;
+            std::nth_element(idx.begin() + lo, idx.begin() + mid, idx.begin() + hi,
+                             [&](uint32_t x, uint32_t y) { return cen[3 * x + a] < cen[3 * y + a]; });
+        }
+        int32_t me = (int32_t)nodes.size();
+        nodes.emplace_back();
+        Box lb, rb;
+        int32_t l = build(lo, mid, &lb, depth + 1);
+        int32_t r = build(mid, hi, &rb, depth + 1);
+        Node64 &nd = nodes[me];
+        for (int i = 0; i < 3; i++) { nd.lmin[i] = lb.mn[i]; nd.lmax[i] = lb.mx[i]; nd.rmin[i] = rb.mn[i]; nd.rmax[i] = rb.mx[i]; }
+        nd.left = l;
+        nd.right = r;
+        nd.pad[0] = nd.pad[1] = 0;
+        return me;
+    }
+};
+
+int fail(std::string *err, int code, const std::string &msg) {
+    if (err) *err = msg;
+    return code;
+}
+
+} // namespace
+
+int ptr_flatten(const PtrFlatScene *fs, HostScene *hs, std::string *err) {
+    if (!fs || !hs) return fail(err, PTR_ERR_INVALID, "null scene");
+    if (fs->n_primitives < 0 || fs->n_meshes < 0 || fs->n_clouds < 0 || fs->n_images < 0)
+        return fail(err, PTR_ERR_INVALID, "negative count in PtrFlatScene");
+    *hs = HostScene();
+
+    for (int i = 0; i < fs->n_images; i++) {
+        const PtrImage &pi = fs->images[i];
+        if (pi.width <= 0 || pi.height <= 0 || !pi.rgb) return fail(err, PTR_ERR_INVALID, "bad image");
+        HostImage im;
+        im.w = pi.width;
+        im.h = pi.height;
+        im.rgb.assign(pi.rgb, pi.rgb + 3 * (size_t)pi.width * pi.height);
+        hs->images.push_back(std::move(im));
+    }
+    /* meshes: vertices to world space (mesh.cpp:55-65), triangles pre-gathered */
+    for (int i = 0; i < fs->n_meshes; i++) {
+        const PtrMesh &pm = fs->meshes[i];
+        if (pm.n_triangles < 0 || pm.n_vertices < 0 || (pm.n_triangles > 0 && (!pm.p || !pm.indices)))
+            return fail(err, PTR_ERR_INVALID, "bad mesh arrays");
+        if (!is_affine(pm.to_world.m) || !is_affine(pm.to_world.mInv)) return fail(err, PTR_ERR_LIMIT, "projective mesh transform");
+        HostMesh hm;
+        hm.tri_base = (int64_t)(hs->tris.size() / 9);
+        hm.n_tris = pm.n_triangles;
+        hm.n_uvs = pm.uv ? pm.n_uvs : 0;
+        std::vector<V3h> wp(pm.n_vertices);
+        for (int v = 0; v < pm.n_vertices; v++) {
+            V3h p = {pm.p[3 * v], pm.p[3 * v + 1], pm.p[3 * v + 2]};
+            wp[v] = xf_point16(pm.to_world.m, p);
+        }
+        hs->tris.reserve(hs->tris.size() + 9 * (size_t)pm.n_triangles);
+        for (int t = 0; t < pm.n_triangles; t++) {
+            for (int c = 0; c < 3; c++) {
+                int vi = pm.indices[9 * (size_t)t + 3 * c];
+                if (vi < 0 || vi >= pm.n_vertices) return fail(err, PTR_ERR_INVALID, "mesh vertex index out of range");
+                hs->tris.push_back(wp[vi].x);
+                hs->tris.push_back(wp[vi].y);
+                hs->tris.push_back(wp[vi].z);
+                hs->uvidx.push_back(pm.indices[9 * (size_t)t + 3 * c + 2]);
+            }
+        }
+        if (pm.uv) {
+            hm.uv.assign(pm.uv, pm.uv + 2 * (size_t)pm.n_uvs);
+            hm.uv.push_back(0.f);
+            hm.uv.push_back(0.f);
+        }
+        hs->meshes.push_back(std::move(hm));
+    }
+    for (int i = 0; i < fs->n_clouds; i++) {
+        const PtrCloud &pc = fs->clouds[i];
+        if (pc.n_particles < 0 || (pc.n_particles > 0 && !pc.positions)) return fail(err, PTR_ERR_INVALID, "bad particle cloud");
+        HostCloud hc;
+        hc.n = pc.n_particles;
+        hc.radius = pc.radius;
+        hc.pos.assign(pc.positions, pc.positions + 3 * (size_t)pc.n_particles);
+        hs->clouds.push_back(std::move(hc));
+    }
+
+    if (fs->camera_medium.is_valid) {
+        hs->view_medium = (int)hs->media.size();
+        hs->media.push_back(conv_medium(fs->camera_medium));
+        hs->has_media = true;
+    }
+
+    std::vector<Box> boxes;      /* one per BVH item */
+    std::vector<Item48> raw;     /* same order as boxes */
+    Box world;
+    world.reset();
+
+    for (int i = 0; i < fs->n_primitives; i++) {
+        const PtrPrimitive &pp = fs->primitives[i];
+        DPrim pr;
+        memset(&pr, 0, sizeof(pr));
+        pr.type = pp.shape_type;
+        pr.geom = pp.geom;
+        pr.material = -1;
+        pr.light = -1;
+        pr.med_inside = pr.med_outside = -1;
+        const PtrTransform *tw = &pp.to_world;
+        PtrTransform ident;
+        bool reverse = pp.reverse_orientation != 0;
+        float lmin[3] = {0, 0, 0}, lmax[3] = {0, 0, 0};
+        bool ok = true;
+        switch (pp.shape_type) {
+        case PTR_SHAPE_SPHERE: /* shape.h:74-78 */
+            pr.p[0] = pp.params[0];
+            pr.p[1] = -pr.p[0];
+            pr.p[2] = pr.p[0];
+            pr.p[3] = acosf(-1.f);
+            pr.p[4] = acosf(1.f);
+            pr.p[5] = radians_f(360);
+            lmin[0] = lmin[1] = -pr.p[0]; lmin[2] = pr.p[1];
+            lmax[0] = lmax[1] = pr.p[0]; lmax[2] = pr.p[2];
+            pr.area = pr.p[5] * pr.p[0] * (pr.p[2] - pr.p[1]); /* sphere.cpp:21-23 */
+            break;
+        case PTR_SHAPE_SPHERE_PROCEDURAL:
+            pr.p[0] = pp.params[0];
+            reverse = false;
+            lmin[0] = lmin[1] = lmin[2] = -pr.p[0];
+            lmax[0] = lmax[1] = lmax[2] = pr.p[0];
+            pr.area = 1; /* procedural.h:59 */
+            break;
+        case PTR_SHAPE_RECTANGLE: { /* shape.h:119-122, rectangle.cpp:37-44 */
+            pr.p[0] = pp.params[0] < 0 ? 0 : pp.params[0];
+            pr.p[1] = pp.params[1] < 0 ? 0 : pp.params[1];
+            float hx = pr.p[0] / 2, hy = pr.p[1] / 2;
+            lmin[0] = -hx; lmin[1] = -hy; lmin[2] = (float)-0.0001;
+            lmax[0] = hx; lmax[1] = hy; lmax[2] = (float)0.0001;
+            pr.area = pr.p[0] * pr.p[1];
+        } break;
+        case PTR_SHAPE_DISK: /* shape.h:96-99, disk.cpp:3-6,46-48 */
+            pr.p[0] = pp.params[0];
+            pr.p[1] = pp.params[1];
+            pr.p[2] = pp.params[2];
+            pr.p[3] = radians_f(clampf(pp.params[3], 0, 360));
+            lmin[0] = lmin[1] = -pr.p[1]; lmin[2] = pr.p[0];
+            lmax[0] = lmax[1] = pr.p[1]; lmax[2] = pr.p[0];
+            pr.area = (float)(pr.p[3] * 0.5 * (pr.p[1] * pr.p[1] - pr.p[2] * pr.p[2]));
+            break;
+        case PTR_SHAPE_BOX_PROCEDURAL:
+            for (int k = 0; k < 3; k++) {
+                pr.p[k] = pp.params[k];
+                float half = (float)(pr.p[k] * 0.5);
+                lmin[k] = -half;
+                lmax[k] = half;
+            }
+            reverse = false;
+            pr.area = 1;
+            break;
+        case PTR_SHAPE_COMPONENT_PROCEDURAL:
+            for (int k = 0; k < 6; k++) pr.p[k] = pp.params[k];
+            for (int k = 0; k < 3; k++) { lmin[k] = pp.params[k]; lmax[k] = pp.params[3 + k]; }
+            pr.toy_id = pp.geom;
+            if (pp.geom != 4) return fail(err, PTR_ERR_LIMIT, "procedural toy ids 0-3 (origami) are not implemented on the device yet");
+            reverse = false;
+            pr.area = 1;
+            break;
+        case PTR_SHAPE_MESH:
+            if (pp.geom < 0 || pp.geom >= fs->n_meshes) return fail(err, PTR_ERR_INVALID, "mesh index out of range");
+            tw = &fs->meshes[pp.geom].to_world;
+            reverse = false;
+            break;
+        case PTR_SHAPE_PARTICLECLOUD: {
+            if (pp.geom < 0 || pp.geom >= fs->n_clouds) return fail(err, PTR_ERR_INVALID, "cloud index out of range");
+            memset(&ident, 0, sizeof(ident));
+            ident.m[0] = ident.m[5] = ident.m[10] = ident.m[15] = 1;
+            ident.mInv[0] = ident.mInv[5] = ident.mInv[10] = ident.mInv[15] = 1;
+            tw = &ident;
+            reverse = false;
+            const HostCloud &c = hs->clouds[pp.geom];
+            pr.p[0] = c.radius;
+            float area = 0; /* particlecloud.cpp:16-29 */
+            for (int k = 0; k < c.n; k++) area += (float)(4 * kPiD * c.radius * c.radius);
+            pr.area = area;
+        } break;
+        default: ok = false; break; /* "Skipping unknown shape type", scene.cpp:911-915 */
+        }
+        if (!ok) continue;
+        if (!is_affine(tw->m) || !is_affine(tw->mInv)) return fail(err, PTR_ERR_LIMIT, "projective primitive transform");
+        copy34(pr.o2w, tw->m);
+        copy34(pr.w2o, tw->mInv);
+        bool swaps = swaps_handedness(tw->m);
+        if (reverse) pr.flags |= PF_REVERSE;
+        if (reverse ^ swaps) pr.flags |= PF_FLIP_N;
+
+        int prim_index = (int)hs->prims.size();
+        Box pb;
+        pb.reset();
+        if (pp.shape_type == PTR_SHAPE_MESH) {
+            const HostMesh &hm = hs->meshes[pp.geom];
+            if (boxes.size() + (size_t)hm.n_tris >= (1u << 27)) return fail(err, PTR_ERR_LIMIT, "more than 2^27 BVH items");
+            for (int t = 0; t < hm.n_tris; t++) {
+                const float *v = &hs->tris[9 * (size_t)(hm.tri_base + t)];
+                Box tb;
+                tb.reset();
+                tb.grow(v);
+                tb.grow(v + 3);
+                tb.grow(v + 6);
+                pb.grow(tb);
+                Item48 it;
+                it.q[0] = v[0]; it.q[1] = v[1]; it.q[2] = v[2]; it.q[3] = as_float(prim_index);
+                it.q[4] = v[3]; it.q[5] = v[4]; it.q[6] = v[5]; it.q[7] = as_float(t);
+                it.q[8] = v[6]; it.q[9] = v[7]; it.q[10] = v[8]; it.q[11] = as_float(ITEM_TRI);
+                boxes.push_back(tb);
+                raw.push_back(it);
+            }
+            if (hm.n_tris == 0) continue; /* an empty mesh has no bounds; the reference would crash */
+        } else if (pp.shape_type == PTR_SHAPE_PARTICLECLOUD) {
+            const HostCloud &c = hs->clouds[pp.geom];
+            if (boxes.size() + (size_t)c.n >= (1u << 27)) return fail(err, PTR_ERR_LIMIT, "more than 2^27 BVH items");
+            for (int k = 0; k < c.n; k++) { /* ParticleCloudGetBounds, particlecloud.cpp:284-293 */
+                Box tb;
+                for (int a = 0; a < 3; a++) {
+                    tb.mn[a] = -c.radius + c.pos[3 * (size_t)k + a];
+                    tb.mx[a] = c.radius + c.pos[3 * (size_t)k + a];
+                }
+                pb.grow(tb);
+                Item48 it;
+                memset(&it, 0, sizeof(it));
+                it.q[0] = c.pos[3 * (size_t)k]; it.q[1] = c.pos[3 * (size_t)k + 1]; it.q[2] = c.pos[3 * (size_t)k + 2];
+                it.q[3] = as_float(prim_index);
+                it.q[4] = c.radius;
+                it.q[7] = as_float(k);
+                it.q[11] = as_float(ITEM_PARTICLE);
+                boxes.push_back(tb);
+                raw.push_back(it);
+            }
+            if (c.n == 0) continue;
+        } else {
+            pb = xf_bounds16(tw->m, lmin, lmax);
+            Item48 it;
+            memset(&it, 0, sizeof(it));
+            it.q[0] = pb.mn[0]; it.q[1] = pb.mn[1]; it.q[2] = pb.mn[2]; it.q[3] = as_float(prim_index);
+            it.q[4] = pb.mx[0]; it.q[5] = pb.mx[1]; it.q[6] = pb.mx[2];
+            it.q[11] = as_float(ITEM_PRIM);
+            boxes.push_back(pb);
+            raw.push_back(it);
+        }
+        for (int a = 0; a < 3; a++) { pr.bmin[a] = pb.mn[a]; pr.bmax[a] = pb.mx[a]; }
+        world.grow(pb);
+
+        /* material / emission / interior medium, scene.cpp:917-944 */
+        int medium = -1;
+        if (pp.mat.is_emissive && !pp.no_mat) {
+            pr.flags |= PF_EMISSIVE;
+            for (int k = 0; k < 3; k++) pr.L[k] = pp.mat.textures[0].spec[k];
+        } else {
+            if (!pp.no_mat && pp.mat.type >= PTR_MAT_MATTE && pp.mat.type <= PTR_MAT_PLAYGROUND) {
+                if (pp.mat.type == PTR_MAT_SUBSURFACE || pp.mat.type == PTR_MAT_KDSUBSURFACE)
+                    return fail(err, PTR_ERR_LIMIT, "subsurface materials are not implemented on the device yet");
+                DMat m;
+                memset(&m, 0, sizeof(m));
+                m.type = pp.mat.type;
+                m.ntex = pp.mat.n_textures;
+                m.id = pp.mat.id;
+                m.table = -1;
+                for (int k = 0; k < 4; k++) m.vals[k] = pp.mat.vals[k];
+                for (int k = 0; k < 16; k++) {
+                    const PtrTexture &t = pp.mat.textures[k];
+                    DTex &d = m.tex[k];
+                    d.type = t.type;
+                    d.image = t.image;
+                    if (t.type == 1) { d.v[0] = t.fval; d.v[1] = d.v[2] = 0; }
+                    else { d.v[0] = t.spec[0]; d.v[1] = t.spec[1]; d.v[2] = t.spec[2]; }
+                    if (t.type == 2 && (t.image < 0 || t.image >= fs->n_images)) return fail(err, PTR_ERR_INVALID, "texture image index out of range");
+                    if (t.type < 0 || t.type > 2) { d.type = 0; }
+                }
+                pr.material = (int)hs->mats.size();
+                hs->mats.push_back(m);
+            }
+            if (pp.medium.is_valid) {
+                medium = (int)hs->media.size();
+                hs->media.push_back(conv_medium(pp.medium));
+                hs->has_media = true;
+            }
+        }
+        pr.med_inside = medium;
+        pr.med_outside = -1;
+        hs->prims.push_back(pr);
+    }
+
+    /* lights: emissive primitives in insertion order, then the light map (primitive.cpp:205-244) */
+    for (size_t i = 0; i < hs->prims.size(); i++) {
+        if (!(hs->prims[i].flags & PF_EMISSIVE)) continue;
+        DLight l;
+        memset(&l, 0, sizeof(l));
+        l.type = LT_AREA;
+        l.prim = (int)i;
+        for (int k = 0; k < 3; k++) l.Lemit[k] = hs->prims[i].L[k];
+        memcpy(l.l2w, hs->prims[i].o2w, sizeof(l.l2w));
+        memcpy(l.w2l, hs->prims[i].w2o, sizeof(l.w2l));
+        hs->prims[i].light = (int)hs->lights.size();
+        hs->lights.push_back(l);
+    }
+    hs->has_env = fs->has_envmap != 0;
+    if (hs->has_env) {
+        const PtrEnvMap &e = fs->envmap;
+        if (e.width <= 0 || e.height <= 0 || e.nu <= 0 || e.nv <= 0 || !e.texels || !e.func || !e.cdf || !e.func_int || !e.marg_cdf)
+            return fail(err, PTR_ERR_INVALID, "bad environment map");
+        if (!is_affine(e.light_to_world.m) || !is_affine(e.light_to_world.mInv)) return fail(err, PTR_ERR_LIMIT, "projective light transform");
+        hs->env_w = e.width; hs->env_h = e.height; hs->env_nu = e.nu; hs->env_nv = e.nv;
+        hs->env_texels.assign(e.texels, e.texels + 3 * (size_t)e.width * e.height);
+        hs->env_func.assign(e.func, e.func + (size_t)e.nu * e.nv);
+        hs->env_cdf.assign(e.cdf, e.cdf + (size_t)(e.nu + 1) * e.nv);
+        hs->env_func_int.assign(e.func_int, e.func_int + e.nv);
+        hs->env_marg_cdf.assign(e.marg_cdf, e.marg_cdf + e.nv + 1);
+        hs->env_marg_int = e.marg_int;
+        DLight l;
+        memset(&l, 0, sizeof(l));
+        l.type = LT_INFINITE;
+        l.prim = -1;
+        copy34(l.l2w, e.light_to_world.m);
+        copy34(l.w2l, e.light_to_world.mInv);
+        /* Bounds3::BoundingSphere (geometry.h) of the world bound, infinite.cpp:52-56 */
+        if (hs->prims.empty()) return fail(err, PTR_ERR_INVALID, "environment map without any primitive");
+        float c[3];
+        bool inside = true;
+        for (int a = 0; a < 3; a++) {
+            c[a] = (world.mn[a] + world.mx[a]) * (1.0f / 2);
+            inside = inside && c[a] >= world.mn[a] && c[a] <= world.mx[a];
+        }
+        float dx = c[0] - world.mx[0], dy = c[1] - world.mx[1], dz = c[2] - world.mx[2];
+        l.worldRadius = inside ? sqrtf(dx * dx + dy * dy + dz * dz) : 0;
+        hs->lights.push_back(l);
+    }
+    if (hs->lights.size() > PTR_MAX_LIGHTS) return fail(err, PTR_ERR_LIMIT, "more than 256 lights (Aggregator::lightList[256])");
+
+    /* the acceleration structure */
+    if (!boxes.empty()) {
+        Builder b(boxes);
+        Box rb;
+        b.nodes.reserve(boxes.size());
+        b.order.reserve(boxes.size());
+        int32_t root = b.build(0, boxes.size(), &rb, 0);
+        if (root != 0) { /* the whole scene fits one leaf: wrap it */
+            Node64 nd;
+            memset(&nd, 0, sizeof(nd));
+            for (int i = 0; i < 3; i++) { nd.lmin[i] = rb.mn[i]; nd.lmax[i] = rb.mx[i]; }
+            nd.left = root;
+            nd.right = BVH_NO_CHILD;
+            b.nodes.clear();
+            b.nodes.push_back(nd);
+        }
+        if (b.max_depth + 2 > BVH_STACK) return fail(err, PTR_ERR_LIMIT, "BVH deeper than the traversal stack");
+        hs->bvh_depth = b.max_depth;
+        hs->nodes = std::move(b.nodes);
+        hs->items.resize(b.order.size());
+        for (size_t i = 0; i < b.order.size(); i++) hs->items[i] = raw[b.order[i]];
+    }
+    return PTR_OK;
+}

@@ -1,0 +1,48 @@
+/*
+ * ptr_host.h — host-side staging of a PtrFlatScene into the flat device tables of dev_scene.h.
+ * Replaces the reference's scene bring-up kernels (MakeSceneGPU / Aggregator::Wrap / MakeLights,
+ * scene.cpp:891-958, primitive.cpp:620-642) and its three median-split BVH builds with ONE
+ * binned-SAH build over triangles, particles and analytic primitives.
+ */
+#pragma once
+#include "../../include/ptr_api.h"
+#include "dev_scene.h"
+#include <string>
+#include <vector>
+
+struct HostImage {
+    std::vector<float> rgb;
+    int w, h;
+};
+struct HostMesh {
+    int64_t tri_base;
+    int n_tris, n_uvs;
+    std::vector<float> uv; /* 2*(n_uvs+1): one pad element, mesh.cpp:76 accepts index == nUvs */
+};
+struct HostCloud {
+    std::vector<float> pos;
+    int n;
+    float radius;
+};
+struct HostScene {
+    std::vector<Node64> nodes;
+    std::vector<Item48> items;
+    std::vector<DPrim> prims;
+    std::vector<DMat> mats;
+    std::vector<DMedium> media;
+    std::vector<DLight> lights;
+    std::vector<HostImage> images;
+    std::vector<HostMesh> meshes;
+    std::vector<HostCloud> clouds;
+    std::vector<float> tris;
+    std::vector<int32_t> uvidx;
+    std::vector<float> env_texels, env_func, env_cdf, env_func_int, env_marg_cdf;
+    float env_marg_int = 0;
+    int env_w = 0, env_h = 0, env_nu = 0, env_nv = 0;
+    int view_medium = -1, has_env = 0;
+    int bvh_depth = 0;
+    bool has_media = false;
+};
+
+/* returns PTR_OK or an error code with *err filled */
+int ptr_flatten(const PtrFlatScene *fs, HostScene *out, std::string *err);

@@ -1,0 +1,319 @@
+/*
+ * pt_scenes.cpp — the benchmark / test scenes, written against the kept scene API exactly the
+ * way src/main.cpp:459-1095 writes its scene functions.  The author's assets (dragon.obj, EXR
+ * sky maps, SPH frames; main.cpp:21-22) are not available, so geometry and the environment map
+ * are synthesised in code with fixed seeds; everything else (cameras, materials,
+ * transforms) follows the cited reference scene.
+ *
+ * A small C interface at the bottom lets Python drive these builders and fetch the flat scene.
+ */
+#include "pt_scene.h"
+#include <cstdint>
+#include <cstdlib>
+
+namespace {
+
+struct Pcg { /* PCG32 for synthetic data only (never on the render path) */
+    uint64_t state, inc;
+    explicit Pcg(uint64_t seed) : state(0), inc((seed << 1u) | 1u) { next(); state += 0x853c49e6748fea9bULL; next(); }
+    uint32_t next() {
+        uint64_t old = state;
+        state = old * 6364136223846793005ULL + inc;
+        uint32_t xs = (uint32_t)(((old >> 18u) ^ old) >> 27u), rot = (uint32_t)(old >> 59u);
+        return (xs >> rot) | (xs << ((32 - rot) & 31));
+    }
+    float uniform() { return (next() >> 8) * (1.0f / 16777216.0f); }
+};
+
+/* analytic sky + sun, equirectangular, stands in for skylight-sunset.exr (main.cpp:479) */
+std::vector<Spectrum> MakeSky(int w, int h) {
+    std::vector<Spectrum> px((size_t)w * h);
+    const double sunTheta = 1.05, sunPhi = 2.2;
+    double sx = std::sin(sunTheta) * std::cos(sunPhi), sy = std::sin(sunTheta) * std::sin(sunPhi), sz = std::cos(sunTheta);
+    for (int v = 0; v < h; v++) {
+        double theta = Pi * (v + 0.5) / h;
+        for (int u = 0; u < w; u++) {
+            double phi = 2 * Pi * (u + 0.5) / w;
+            double dx = std::sin(theta) * std::cos(phi), dy = std::sin(theta) * std::sin(phi), dz = std::cos(theta);
+            double up = dz; /* light-space +z is "up" after the scene's RotateX(-95) */
+            double t = 0.5 * (up + 1.0);
+            double r = (1 - t) * 0.95 + t * 0.35, g = (1 - t) * 0.75 + t * 0.55, b = (1 - t) * 0.55 + t * 0.95;
+            if (up < 0) { r *= 0.15; g *= 0.15; b *= 0.15; } /* dark ground half, like the half-black EXRs (light.h:86-92) */
+            double c = dx * sx + dy * sy + dz * sz;
+            double sun = c > 0 ? std::pow(c, 400.0) * 40.0 + std::pow(c, 12.0) * 0.6 : 0;
+            px[(size_t)v * w + u] = Spectrum((Float)(r + sun), (Float)(g + 0.9 * sun), (Float)(b + 0.7 * sun));
+        }
+    }
+    return px;
+}
+
+/* closed (2,3) torus-knot tube, nu x nv quads -> 2*nu*nv triangles (660x660 -> 871,200) */
+ParsedMesh *MakeKnotMesh(int nu, int nv, uint64_t seed, const Transform &toWorld) {
+    std::vector<Point3f> P((size_t)nu * nv);
+    std::vector<Point3i> I((size_t)nu * nv * 6);
+    Pcg rng(seed);
+    const double tube = 0.42;
+    for (int i = 0; i < nu; i++) {
+        double t = 2 * Pi * i / nu;
+        auto curve = [](double s, double *o) {
+            double r = 2 + std::cos(3 * s);
+            o[0] = r * std::cos(2 * s); o[1] = r * std::sin(2 * s); o[2] = 1.2 * std::sin(3 * s);
+        };
+        double c[3], c1[3];
+        curve(t, c);
+        curve(t + 1e-4, c1);
+        double T[3] = {c1[0] - c[0], c1[1] - c[1], c1[2] - c[2]};
+        double tl = std::sqrt(T[0] * T[0] + T[1] * T[1] + T[2] * T[2]);
+        for (double &x : T) x /= tl;
+        double N[3] = {-c[0], -c[1], 0}; /* towards the axis, made orthogonal to T */
+        double d = N[0] * T[0] + N[1] * T[1] + N[2] * T[2];
+        for (int k = 0; k < 3; k++) N[k] -= d * T[k];
+        double nl = std::sqrt(N[0] * N[0] + N[1] * N[1] + N[2] * N[2]);
+        for (double &x : N) x /= nl;
+        double B[3] = {T[1] * N[2] - T[2] * N[1], T[2] * N[0] - T[0] * N[2], T[0] * N[1] - T[1] * N[0]};
+        for (int j = 0; j < nv; j++) {
+            double a = 2 * Pi * j / nv;
+            double rr = tube * (1.0 + 0.04 * std::sin(9 * a + 5 * t)) + 0.004 * (rng.uniform() - 0.5);
+            double ca = std::cos(a) * rr, sa = std::sin(a) * rr;
+            P[(size_t)i * nv + j] = Point3f((Float)(c[0] + ca * N[0] + sa * B[0]), (Float)(c[1] + ca * N[1] + sa * B[1]),
+                                            (Float)(c[2] + ca * N[2] + sa * B[2]));
+        }
+    }
+    size_t k = 0;
+    for (int i = 0; i < nu; i++)
+        for (int j = 0; j < nv; j++) {
+            int i1 = (i + 1) % nu, j1 = (j + 1) % nv;
+            int a = i * nv + j, b = i1 * nv + j, c = i1 * nv + j1, d = i * nv + j1;
+            I[k++] = Point3i(a, 0, 0); I[k++] = Point3i(b, 0, 0); I[k++] = Point3i(c, 0, 0);
+            I[k++] = Point3i(a, 0, 0); I[k++] = Point3i(c, 0, 0); I[k++] = Point3i(d, 0, 0);
+        }
+    return ParsedMeshFromData(toWorld, nu * nv * 2, I.data(), nu * nv, P.data());
+}
+
+/* ---- scenes --------------------------------------------------------------------------------- */
+
+/* c1: geometry of CornellRoomBasic (main.cpp:748-802); variant bit 0 keeps the mirror box and
+ * adds the glass material the reference declares; otherwise both boxes are white matte and the
+ * textured floor is white (no assets), as SURVEY §8d prescribes. */
+void CornellScene(Camera *camera, Float aspect, int variant) {
+    camera->Config(Point3f(0, 4, -25), Point3f(0, 4, 0.0f), vec3f(0, 1, 0), 40, aspect);
+    MaterialDescriptor white = MakeMatteMaterial(Spectrum(.73, .73, .73));
+    MaterialDescriptor green = MakeMatteMaterial(Spectrum(.05, .65, .05));
+    MaterialDescriptor red = MakeMatteMaterial(Spectrum(.65, .05, .05));
+    MaterialDescriptor mirror = MakeMirrorMaterial(Spectrum(.9));
+    MaterialDescriptor glass = MakeGlassMaterial(Spectrum(1), Spectrum(1), 1.34);
+    Float height = 14;
+    Float width = height * 1.2;
+    Float extend = 30;
+    InsertPrimitive(MakeRectangle(Translate(0, height / 2, 0) * RotateY(0), width, height), white);
+    InsertPrimitive(MakeRectangle(Translate(-width / 2, height / 2, -height / 2) * RotateY(90), width + extend, height), red);
+    InsertPrimitive(MakeRectangle(Translate(width / 2, height / 2, -height / 2) * RotateY(90), width + extend, height), green);
+    Float bottomExt = 5;
+    InsertPrimitive(MakeRectangle(Translate(0, 0, -(height + bottomExt) / 2) * RotateX(90), width, height + bottomExt), white);
+    InsertPrimitive(MakeRectangle(Translate(0, height / 2, -28), width, height), white);
+    InsertPrimitive(MakeRectangle(Translate(0, height, -height / 2) * RotateX(90), width, height), white);
+    InsertPrimitive(MakeBox(Translate(-3.5, 2, -width * 0.5) * RotateY(-25), 4, 4, 4), (variant & 1) ? glass : white);
+    InsertPrimitive(MakeBox(Translate(3.0, 4.25, -width * 0.25) * RotateY(30), 4.5, 8.5, 4.5), (variant & 1) ? mirror : white);
+    MaterialDescriptor matEm = MakeEmissive(Spectrum(0.992, 0.964, 0.390) * 6);
+    InsertPrimitive(MakeDisk(Translate(0, height - 0.01, -height / 2) * RotateX(90), 0, width * 0.15, 0.f, 360), matEm);
+    if (variant & 2) InsertCameraMedium(MakeMedium(Spectrum(.008), Spectrum(.01), 0)); /* CornellRoomSkull, main.cpp:851 */
+}
+
+/* c2: DragonScene (main.cpp:459-487) with the knot mesh standing in for dragon.obj and the
+ * analytic sky for skylight-sunset.exr.  variant: 0 = microfacet glass, 1 = plastic (as shipped),
+ * 2 = specular glass, 3 = matte. */
+void KnotScene(Camera *camera, Float aspect, int segments, int variant) {
+    camera->Config(Point3f(60.f, 69.f, -43.f), Point3f(-12.12833, 0., 3.16229), vec3f(0.f, 1.f, 0.f), 38.f, aspect);
+    MaterialDescriptor gray = MakePlasticMaterial(Spectrum(.1, .1, .1), Spectrum(.7, .7, .7), 0.1);
+    MaterialDescriptor blue = MakePlasticMaterial(Spectrum(.1f, .1f, .4f), Spectrum(0.6f), 0.03);
+    MaterialDescriptor mglass = MakeGlassMaterial(Spectrum(1), Spectrum(1), 1.5, .05, .05);
+    MaterialDescriptor sglass = MakeGlassMaterial(Spectrum(1), Spectrum(1), 1.5);
+    MaterialDescriptor matte = MakeMatteMaterial(Spectrum(.6, .5, .4));
+    SphereDescriptor bottomWall = MakeSphere(Translate(0, -1500, 0), 1500);
+    static std::vector<Spectrum> sky;
+    if (sky.empty()) sky = MakeSky(512, 256);
+    InsertLightMap(sky.data(), 512, 256, RotateX(-95) * RotateZ(50), Spectrum(2.5));
+    Transform toWorld = Translate(-12, 18, 3) * Scale(7.5) * RotateZ(-1) * RotateY(70) * RotateX(90);
+    ParsedMesh *mesh = MakeKnotMesh(segments, segments, 7, toWorld);
+    MeshDescriptor knot = MakeMesh(mesh);
+    InsertPrimitive(knot, variant == 0 ? mglass : (variant == 1 ? blue : (variant == 2 ? sglass : matte)));
+    InsertPrimitive(bottomWall, gray);
+}
+
+/* material zoo on spheres/disks/rects under an area light + sky: exercises every BxDF the
+ * materials instantiate (BoxesScene-like, main.cpp:489-570, small) */
+void ZooScene(Camera *camera, Float aspect, int variant) {
+    camera->Config(Point3f(0, 9, -26), Point3f(0, 3, 0), vec3f(0, 1, 0), 40, aspect);
+    MaterialDescriptor mats[] = {
+        MakeMatteMaterial(Spectrum(.7, .3, .2), 0),
+        MakeMatteMaterial(Spectrum(.3, .6, .3), 0.4),
+        MakeMirrorMaterial(Spectrum(.9)),
+        MakeGlassMaterial(Spectrum(1), Spectrum(1), 1.5),
+        MakeGlassMaterial(Spectrum(.9), Spectrum(.95), 1.5, .1, .2),
+        MakeMetalMaterial(Spectrum(.2, .92, 1.1), Spectrum(3.9, 2.45, 2.14), .05, .05),
+        MakePlasticMaterial(Spectrum(.2, .2, .7), Spectrum(.6), 0.1),
+        MakeUberMaterial(Spectrum(.25, .5, .25), Spectrum(.3), Spectrum(.1), Spectrum(.2), .1, .1, Spectrum(.9), 1.4),
+        MakeTranslucentMaterial(Spectrum(.5, .4, .3), Spectrum(.3), Spectrum(.6), Spectrum(.4), .2),
+        MakePlayGroundMaterial(Spectrum(.85, .42, .52)),
+    };
+    int n = sizeof(mats) / sizeof(mats[0]);
+    for (int i = 0; i < n; i++) {
+        Float x = -9.f + 4.5f * (i % 5), z = (i / 5) * 5.f - 2.f;
+        if (i % 3 == 2) InsertPrimitive(MakeBox(Translate(x, 1.5, z) * RotateY(20 + 10 * i), 2.6, 3, 2.6), mats[i]);
+        else InsertPrimitive(MakeSphere(Translate(x, 1.6, z), 1.6), mats[i]);
+    }
+    InsertPrimitive(MakeRectangle(Translate(0, 0, 0) * RotateX(90), 60, 60), MakeMatteMaterial(Spectrum(.6)));
+    InsertPrimitive(MakeRectangle(Translate(0, 8, 12), 60, 30), MakePlasticMaterial(Spectrum(.4, .4, .45), Spectrum(.3), 0.2));
+    InsertPrimitive(MakeDisk(Translate(0, 14, 0) * RotateX(90), 0, 4, 1, 300), MakeEmissive(Spectrum(9, 8.5, 7)));
+    InsertPrimitive(MakeSphere(Translate(8, 9, -4), 1.0), MakeEmissive(Spectrum(12, 10, 6)));
+    if (variant & 1) {
+        static std::vector<Spectrum> sky;
+        if (sky.empty()) sky = MakeSky(256, 128);
+        InsertLightMap(sky.data(), 256, 128, RotateX(-90) * RotateZ(90), Spectrum(1.0));
+    }
+    if (variant & 2) InsertCameraMedium(MakeMedium(Spectrum(.004), Spectrum(.012), 0.3));
+}
+
+/* c5 (volume half): VolumetricCausticsScene verbatim, main.cpp:987-1021 */
+void VolumetricCausticsScene(Camera *camera, Float aspect) {
+    camera->Config(Point3f(0.f, 18.f, 70.f), Point3f(0, 21.15341, 0), vec3f(0.f, 1.f, 0.f), 40.f, aspect);
+    MaterialDescriptor yellow = MakeMatteMaterial(Spectrum(.7, .7, .0));
+    MaterialDescriptor greenGlass = MakeGlassMaterial(Spectrum(1), Spectrum(1), 1.5);
+    Transform er = Translate(0, -1.29, 0) * RotateX(90);
+    RectDescriptor bottomWall = MakeRectangle(er, 1000, 1000);
+    InsertPrimitive(bottomWall, yellow);
+    MaterialDescriptor matEm = MakeEmissive(Spectrum(0.992, 0.964, 0.890) * 35);
+    SphereDescriptor lightSphere = MakeSphere(Translate(15, 60, 3), 4);
+    SphereDescriptor lightSphere2 = MakeSphere(Translate(-15, 60, 3), 4);
+    InsertPrimitive(lightSphere, matEm);
+    InsertPrimitive(lightSphere2, matEm);
+    MediumDescriptor medium = MakeMedium(Spectrum(.0007), Spectrum(0.005), 0);
+    Transform glassT = Translate(0, 26, 0) * RotateY(45);
+    SphereDescriptor spehre = MakeSphere(glassT, 13);
+    InsertPrimitive(spehre, greenGlass);
+    InsertCameraMedium(medium);
+}
+
+/* c4 stand-in: FluidDragonInBox (main.cpp:1023-1095) with a synthetic dam-break column:
+ * jittered lattice in an L-shaped region of the 2.25 x 2.85 x 4.9 box, radius 0.012, split in
+ * six colour classes by height. */
+static std::vector<std::vector<vec3f>> g_cloudStore;
+void FluidScene(Camera *camera, Float aspect, int nParticles) {
+    camera->Config(Point3f(0.f, 1.5f, 7.0f), Point3f(0.f, -0.5f, 0.f), vec3f(0.f, 1.f, 0.f), 35.f, aspect);
+    MaterialDescriptor white = MakeMatteMaterial(Spectrum(2.0));
+    Float radius = 0.012;
+    MaterialDescriptor materials[] = {
+        MakeMatteMaterial(Spectrum(0.97, 0.00, 0.10)), MakeMatteMaterial(Spectrum(0.90, 0.44, 0.10)),
+        MakeMatteMaterial(Spectrum(0.95, 0.76, 0.30)), MakeMatteMaterial(Spectrum(0.45, 0.70, 0.84)),
+        MakeMatteMaterial(Spectrum(0.15, 0.40, 0.74)), MakeMatteMaterial(Spectrum(0.78, 0.78, 0.74))};
+    g_cloudStore.assign(6, std::vector<vec3f>());
+    Pcg rng(11);
+    const float bx = 2.25052f * 0.5f, by = 2.85056f * 0.5f, bz = 4.90718f * 0.5f;
+    /* L-shape: a tall column near -z plus a shallow pool over the rest */
+    double vol = (2 * bx) * (2 * by) * (0.35 * 2 * bz) + (2 * bx) * (0.25 * 2 * by) * (0.65 * 2 * bz);
+    double spacing = std::cbrt(vol / (nParticles > 0 ? nParticles : 1));
+    int made = 0;
+    for (double y = -by + radius; y < by && made < nParticles; y += spacing)
+        for (double z = -bz + radius; z < bz && made < nParticles; z += spacing) {
+            bool column = z < -bz + 0.35 * 2 * bz;
+            if (!column && y > -by + 0.25 * 2 * by) continue;
+            for (double x = -bx + radius; x < bx && made < nParticles; x += spacing) {
+                vec3f p((Float)(x + 0.3 * spacing * (rng.uniform() - .5f)), (Float)(y + 0.3 * spacing * (rng.uniform() - .5f)),
+                        (Float)(z + 0.3 * spacing * (rng.uniform() - .5f)));
+                int level = (int)(6 * (y + by) / (2 * by));
+                if (level > 5) level = 5;
+                g_cloudStore[level].push_back(p);
+                made++;
+            }
+        }
+    for (int l = 0; l < 6; l++) {
+        if (g_cloudStore[l].empty()) continue;
+        ParticleCloudDescripor desc = MakeParticleCloud(g_cloudStore[l].data(), (int)g_cloudStore[l].size(), radius);
+        InsertPrimitive(desc, materials[l]);
+    }
+    static std::vector<Spectrum> sky;
+    if (sky.empty()) sky = MakeSky(512, 256);
+    InsertLightMap(sky.data(), 512, 256, RotateX(-90) * RotateZ(90), Spectrum(2.5));
+    InsertPrimitive(MakeRectangle(Translate(0, -1.43, 0) * RotateX(90), 100, 100), white);
+    InsertPrimitive(MakeRectangle(Translate(0, 0, -20), 100, 100), white);
+}
+
+/* c5 (subsurface half): SubsurfaceSpheres (main.cpp:914-952) + a KdSubsurface knot */
+void SubsurfaceScene(Camera *camera, Float aspect, int segments) {
+    camera->Config(Point3f(0.f, 62.f, 90.f), Point3f(-10, 0, -20), vec3f(0.f, 1.f, 0.f), 42.f, aspect);
+    MaterialDescriptor gray = MakePlasticMaterial(Spectrum(.1), Spectrum(.7), 0.1);
+    InsertPrimitive(MakeRectangle(Translate(0, 0, 0) * RotateX(90), 1000, 1000), gray);
+    MaterialDescriptor ket = MakeSubsurfaceMaterial("Ketchup", 1, 1.33, 0, 0.05, 0.05);
+    MaterialDescriptor spec = MakeKdSubsurfaceMaterial(Spectrum(.2, .5, .7), Spectrum(1), Spectrum(1), Spectrum(.1), 0.05, 0.05, 1.33, 1);
+    MaterialDescriptor kd0 = MakeKdSubsurfaceMaterial(Spectrum(.2, .5, .7), Spectrum(1), Spectrum(1), Spectrum(.1), 0, 0, 1.33, 1);
+    MaterialDescriptor apple = MakeSubsurfaceMaterial("Apple", 1, 1.33, 0, 0.05, 0.05);
+    static std::vector<Spectrum> sky;
+    if (sky.empty()) sky = MakeSky(512, 256);
+    InsertLightMap(sky.data(), 512, 256, RotateX(-90) * RotateZ(90), Spectrum(2.5));
+    InsertPrimitive(MakeSphere(Translate(20, 20, 10), 18), ket);
+    InsertPrimitive(MakeSphere(Translate(-30, 20, 10), 18), apple);
+    InsertPrimitive(MakeSphere(Translate(6, 20, -20), 18), spec);
+    if (segments > 0) {
+        Transform toWorld = Translate(-60, 22, -20) * Scale(6.0) * RotateX(90);
+        InsertPrimitive(MakeMesh(MakeKnotMesh(segments, segments, 9, toWorld)), kd0);
+    } else InsertPrimitive(MakeSphere(Translate(-60, 20, -20), 18), kd0);
+}
+
+struct BuiltScene {
+    FlatSceneHolder *flat;
+    Camera camera;
+    int rand_calls; /* host rand() calls the scene function made before the BVH build */
+};
+
+} // namespace
+
+extern "C" {
+
+/* name: "cornell" | "knot" | "zoo" | "volcaustic" | "fluid" | "subsurface"; p0/p1: size and variant */
+void *pth_scene_build(const char *name, int width, int height, int p0, int p1) {
+    std::string n(name);
+    BuiltScene *b = new BuiltScene();
+    b->rand_calls = 0;
+    Float aspect = (Float)width / (Float)height;
+    Aggregator dummy;
+    dummy.ctx = (PtrContext *)1; /* do not create a GPU context just to describe a scene */
+    BeginScene(&dummy);
+    if (n == "cornell") CornellScene(&b->camera, aspect, p1);
+    else if (n == "knot") KnotScene(&b->camera, aspect, p0 > 0 ? p0 : 660, p1);
+    else if (n == "zoo") ZooScene(&b->camera, aspect, p1);
+    else if (n == "volcaustic") VolumetricCausticsScene(&b->camera, aspect);
+    else if (n == "fluid") FluidScene(&b->camera, aspect, p0 > 0 ? p0 : 4000000);
+    else if (n == "subsurface") SubsurfaceScene(&b->camera, aspect, p0);
+    else { delete b; return nullptr; }
+    b->flat = FlattenScene();
+    return b;
+}
+const PtrFlatScene *pth_scene_flat(void *h) { return FlatSceneGet(((BuiltScene *)h)->flat); }
+void pth_scene_camera(void *h, PtrCamera *out) { *out = CameraToFlat(((BuiltScene *)h)->camera); }
+int pth_scene_rand_calls(void *h) { return ((BuiltScene *)h)->rand_calls; }
+void pth_scene_free(void *h) {
+    BuiltScene *b = (BuiltScene *)h;
+    FlatSceneFree(b->flat);
+    delete b;
+}
+
+/* transform factories exposed for the boundary unit tests */
+void pth_transform(const char *kind, float a, float b, float c, float d, PtrTransform *out) {
+    std::string k(kind);
+    Transform t;
+    if (k == "translate") t = Translate(a, b, c);
+    else if (k == "scale") t = Scale(a, b, c);
+    else if (k == "rotx") t = RotateX(a);
+    else if (k == "roty") t = RotateY(a);
+    else if (k == "rotz") t = RotateZ(a);
+    else if (k == "rotate") t = Rotate(a, vec3f(b, c, d));
+    else if (k == "trs") t = Translate(a, b, c) * RotateY(d) * Scale(2, 3, 4);
+    *out = TransformToFlat(t);
+}
+void pth_camera_config(const float *eye, const float *at, const float *up, float fov, float aspect, float aperture, PtrCamera *out) {
+    Camera c;
+    if (aperture > 0) c.Config(Point3f(eye[0], eye[1], eye[2]), Point3f(at[0], at[1], at[2]), vec3f(up[0], up[1], up[2]), fov, aspect, aperture);
+    else c.Config(Point3f(eye[0], eye[1], eye[2]), Point3f(at[0], at[1], at[2]), vec3f(up[0], up[1], up[2]), fov, aspect);
+    *out = CameraToFlat(c);
+}
+}
