@@ -1,7 +1,7 @@
 /*
  * dev_bsdf.h — BSDF construction, evaluation and sampling on gfx950.
  * Reference: src/core/reflection.cpp:36-701 (lobes, BSDF), src/core/microfacet.cpp:3-120,
- * src/core/material.cpp:5-86 (Fresnel), src/materials/*.cpp (material -> lobes),
+ * src/core/material.cpp:5-86 (Fresnel), src/materials/ (all files) (material -> lobes),
  * src/core/texture.h:18-84 (textures).  The reference's BSDF holds 8 x 144-byte tagged-union
  * BxDFs by value (1480 B); here a lobe is 80 B and a BSDF holds at most 5 (the most any
  * material pushes: Uber), which keeps the whole BSDF in registers / a small scratch frame.
@@ -477,7 +477,7 @@ struct BssrdfParams {
 };
 
 /* Primitive::ComputeScatteringFunctions -> Material switch -> per-material builders
- * (primitive.cpp:89-106, material.cpp:103-165, materials/*.cpp).  Returns false for an emitter
+ * (primitive.cpp:89-106, material.cpp:103-165, materials/).  Returns false for an emitter
  * (whose single invalidated lobe matches nothing: the path ends there). */
 PD bool compute_scattering(const DScene &sc, const SI &si, BSDF *bsdf, BssrdfParams *bp) {
     const DPrim &pr = sc.prims[si.prim];

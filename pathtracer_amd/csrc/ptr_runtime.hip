@@ -1,0 +1,775 @@
+/*
+ * ptr_runtime.hip — kernels of the wavefront pipeline and the C-ABI of include/ptr_api.h.
+ *
+ * Reference launch sites replaced: SetupPixels<<<>>> (main.cpp:38-53), Render<<<>>>
+ * (main.cpp:421-457) and the scene bring-up kernels (scene.cpp:960-987).  The reference's Render
+ * is one megakernel, a thread per pixel looping over samples and bounces; here one "pass" carries
+ * a batch of pixel-samples through
+ *     raygen -> { trace_closest -> shade -> nee } per bounce -> film
+ * with compacted queues of live paths between the stages, so the traversal kernel runs with full
+ * wavefronts and small per-lane state.
+ */
+#include "dev_path.h"
+#include "ptr_host.h"
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+/* ------------------------------------------------------------------------------------------
+ * device helpers
+ * ---------------------------------------------------------------------------------------- */
+#define TPB 256
+
+struct Pipe {
+    float *ro, *rd;      /* 3 planes of cap floats each */
+    int *hprim, *hface;
+    float *ht;
+    PathRec *paths;
+    NeeRec *nee;
+    int cap;
+};
+struct PassParams {
+    uint64_t seed;
+    int npix, width, height;
+    int sample_first, sample_step; /* sample of slot = sample_first + (slot / npix) * sample_step */
+    int integrator;
+};
+
+__device__ __forceinline__ unsigned wave_sum(unsigned v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ void ctr_flush(unsigned long long *ctrs, int idx, unsigned v) {
+    unsigned s = wave_sum(v);
+    if (__lane_id() == 0 && s) atomicAdd(&ctrs[idx], (unsigned long long)s);
+}
+/* wave-aggregated append: one atomic per wavefront */
+__device__ __forceinline__ void queue_append(int *counter, int *queue, bool pred, int value) {
+    unsigned long long mask = __ballot(pred);
+    if (mask == 0) return;
+    int lane = __lane_id();
+    int leader = __ffsll((long long)mask) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, __popcll(mask));
+    base = __shfl(base, leader, 64);
+    if (pred) {
+        unsigned long long lower = mask & ((1ull << lane) - 1ull);
+        queue[base + __popcll(lower)] = value;
+    }
+}
+
+enum { C_TOTAL = 0, C_MISS, C_SURF, C_MED, C_LIGHT, C_ZERO, C_SHADOW, C_MIS, C_PROBE, C_CAMERA, C_NODES, C_PRIMS, C_COUNT };
+
+PD void camera_ray(const DCamera &c, const PassParams &pp, int pixel, int sample, f3 *o, f3 *d, float *weight) {
+    int i = pixel % pp.width, j = pixel / pp.width;
+    Rng st = make_rng(pp.seed, (uint32_t)pixel, (uint32_t)sample);
+    /* main.cpp:436-443 */
+    float u0 = (float)i / (float)pp.width;
+    float u1 = (float)j / (float)pp.height;
+    float u = ((float)i + st.next()) / (float)pp.width;
+    float v = ((float)j + st.next()) / (float)pp.height;
+    float py = st.next(), px = st.next();
+    f2 disk = concentric_sample_disk(f2(px, py));
+    /* Camera::SpawnRay, camera.cpp:219-224 */
+    f2 rdk = c.lens_radius * disk;
+    f3 cu = ld3(c.u), cv = ld3(c.v), pos = ld3(c.position);
+    f3 offset = cu * rdk.x + cv * rdk.y;
+    f3 dir = ld3(c.lower_left) + u * ld3(c.horizontal) + v * ld3(c.vertical) - pos - offset;
+    *o = pos + offset;
+    *d = normalize(dir);
+    /* GetFilterWeight, main.cpp:412-419 */
+    float x = absr(u - u0);
+    float y = absr(v - u1);
+    float alpha = 2.f;
+    float e = expf(-alpha);
+    *weight = fmaxr(0.f, float(expf(-alpha * x * x) - e)) * fmaxr(0.f, float(expf(-alpha * y * y) - e));
+}
+
+/* ------------------------------------------------------------------------------------------
+ * kernels
+ * ---------------------------------------------------------------------------------------- */
+__global__ void __launch_bounds__(TPB) k_raygen(DScene sc, DCamera cam, Pipe pp, PassParams prm, int n) {
+    int slot = blockIdx.x * TPB + threadIdx.x;
+    if (slot >= n) return;
+    int pixel = slot % prm.npix;
+    int sample = prm.sample_first + (slot / prm.npix) * prm.sample_step;
+    f3 o, d;
+    float w;
+    camera_ray(cam, prm, pixel, sample, &o, &d, &w);
+    int cap = pp.cap;
+    pp.ro[slot] = o.x; pp.ro[cap + slot] = o.y; pp.ro[2 * cap + slot] = o.z;
+    pp.rd[slot] = d.x; pp.rd[cap + slot] = d.y; pp.rd[2 * cap + slot] = d.z;
+    PathRec ps;
+    ps.L[0] = ps.L[1] = ps.L[2] = 0;
+    ps.beta[0] = ps.beta[1] = ps.beta[2] = 1;
+    ps.bounces = 0;
+    ps.flags = 0;
+    ps.dim = 0; /* the integrator restarts the pixel's stream: Render() hands Li a copy-by-value state, main.cpp:433-447 */
+    ps.medium = sc.view_medium;
+    ps.weight = w;
+    ps.pad = 0;
+    pp.paths[slot] = ps;
+}
+
+/* ray generation alone, SoA planes of n = npix (ptr_generate_rays) */
+__global__ void __launch_bounds__(TPB) k_raygen_only(DCamera cam, PassParams prm, int sample, float *o_out, float *d_out, float *w_out) {
+    int p = blockIdx.x * TPB + threadIdx.x;
+    int n = prm.npix;
+    if (p >= n) return;
+    f3 o, d;
+    float w;
+    camera_ray(cam, prm, p, sample, &o, &d, &w);
+    o_out[p] = o.x; o_out[n + p] = o.y; o_out[2 * n + p] = o.z;
+    d_out[p] = d.x; d_out[n + p] = d.y; d_out[2 * n + p] = d.z;
+    if (w_out) w_out[p] = w;
+}
+
+/* Aggregator::Intersect over a batch: rays in SoA planes with plane stride `stride`; `queue`
+ * (optional) lists the ray slots to trace.  Outputs are indexed by slot. */
+template <bool COUNT>
+__global__ void __launch_bounds__(TPB) k_trace_closest(DScene sc, int n, const int *queue, int stride, const float *o, const float *d,
+                                                       const float *tmax_in, int *hprim, int *hface, float *ht, float *hb0, float *hb1,
+                                                       unsigned long long *ctrs) {
+    int i = blockIdx.x * TPB + threadIdx.x;
+    TraceStats st;
+    st.nodes = 0;
+    st.items = 0;
+    if (i < n) {
+        int slot = queue ? queue[i] : i;
+        f3 ro(o[slot], o[stride + slot], o[2 * stride + slot]);
+        f3 rd(d[slot], d[stride + slot], d[2 * stride + slot]);
+        float tmax = tmax_in ? tmax_in[slot] : kInfinity;
+        int hp = -1, hf = -1;
+        float b0 = 0, b1 = 0;
+        bool hit = traverse<false, COUNT>(sc, ro, rd, tmax, hp, hf, b0, b1, &st);
+        hprim[slot] = hit ? hp : -1;
+        hface[slot] = hit ? hf : -1;
+        ht[slot] = tmax;
+        if (hb0) hb0[slot] = hit ? b0 : 0;
+        if (hb1) hb1[slot] = hit ? b1 : 0;
+    }
+    if (COUNT) {
+        ctr_flush(ctrs, C_NODES, st.nodes);
+        ctr_flush(ctrs, C_PRIMS, st.items);
+    }
+}
+
+__global__ void __launch_bounds__(TPB) k_trace_occluded(DScene sc, int n, const float *o, const float *d, const float *tmax_in, int *occ) {
+    int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    f3 ro(o[i], o[n + i], o[2 * n + i]);
+    f3 rd(d[i], d[n + i], d[2 * n + i]);
+    float tmax = tmax_in ? tmax_in[i] : kInfinity;
+    int hp = -1, hf = -1;
+    float b0, b1;
+    occ[i] = traverse<true, false>(sc, ro, rd, tmax, hp, hf, b0, b1, nullptr) ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(TPB) k_shade(DScene sc, Pipe pp, PassParams prm, int n, const int *queue, int *q_next, int *q_nee,
+                                               int *counts, unsigned long long *ctrs) {
+    int i = blockIdx.x * TPB + threadIdx.x;
+    VertexCtr ctr;
+    ctr.total = ctr.miss = ctr.surf = ctr.med = ctr.light = ctr.zero = 0;
+    bool alive = false, want_nee = false;
+    int slot = 0;
+    if (i < n) {
+        slot = queue ? queue[i] : i;
+        int cap = pp.cap;
+        PathRec ps = pp.paths[slot];
+        f3 ro(pp.ro[slot], pp.ro[cap + slot], pp.ro[2 * cap + slot]);
+        f3 rd(pp.rd[slot], pp.rd[cap + slot], pp.rd[2 * cap + slot]);
+        int pixel = slot % prm.npix;
+        int sample = prm.sample_first + (slot / prm.npix) * prm.sample_step;
+        Rng rng = make_rng(prm.seed, (uint32_t)pixel, (uint32_t)sample);
+        rng.dim = (uint32_t)ps.dim;
+        f3 L = ld3(ps.L), beta = ld3(ps.beta);
+        int med = ps.medium, bounces = ps.bounces, pflags = ps.flags;
+        VertexOut vo = shade_vertex(sc, prm.integrator, rng, ro, rd, med, pp.hprim[slot], pp.hface[slot], pp.ht[slot], L, beta, bounces,
+                                    pflags, &pp.nee[slot], ctr);
+        alive = vo.alive;
+        want_nee = vo.want_nee;
+        st3(ps.L, L);
+        st3(ps.beta, beta);
+        ps.medium = med;
+        ps.bounces = bounces;
+        ps.flags = pflags;
+        ps.dim = (int)rng.dim;
+        pp.paths[slot] = ps;
+        if (alive) {
+            pp.ro[slot] = ro.x; pp.ro[cap + slot] = ro.y; pp.ro[2 * cap + slot] = ro.z;
+            pp.rd[slot] = rd.x; pp.rd[cap + slot] = rd.y; pp.rd[2 * cap + slot] = rd.z;
+        }
+    }
+    queue_append(&counts[0], q_next, alive, slot);
+    queue_append(&counts[1], q_nee, want_nee, slot);
+    ctr_flush(ctrs, C_TOTAL, ctr.total);
+    ctr_flush(ctrs, C_MISS, ctr.miss);
+    ctr_flush(ctrs, C_SURF, ctr.surf);
+    ctr_flush(ctrs, C_MED, ctr.med);
+    ctr_flush(ctrs, C_LIGHT, ctr.light);
+    ctr_flush(ctrs, C_ZERO, ctr.zero);
+}
+
+__global__ void __launch_bounds__(TPB) k_nee(DScene sc, Pipe pp, int n, const int *queue, unsigned long long *ctrs) {
+    int i = blockIdx.x * TPB + threadIdx.x;
+    NeeCtr ctr;
+    ctr.shadow = ctr.mis = ctr.zero = 0;
+    if (i < n) {
+        int slot = queue[i];
+        f3 Ld = resolve_nee(sc, pp.nee[slot], ctr);
+        PathRec *ps = &pp.paths[slot];
+        f3 L = ld3(ps->L);
+        L += Ld;
+        st3(ps->L, L);
+    }
+    ctr_flush(ctrs, C_SHADOW, ctr.shadow);
+    ctr_flush(ctrs, C_MIS, ctr.mis);
+    ctr_flush(ctrs, C_ZERO, ctr.zero);
+}
+
+/* Render()'s accumulation (main.cpp:449-455): we += weight * L per sample, in sample order */
+__global__ void __launch_bounds__(TPB) k_film(Pipe pp, int npix, int nbatch, float *we, double *acc, long long *samples) {
+    int p = blockIdx.x * TPB + threadIdx.x;
+    if (p >= npix) return;
+    f3 out(we[3 * p], we[3 * p + 1], we[3 * p + 2]);
+    double a = acc[p];
+    for (int b = 0; b < nbatch; b++) {
+        const PathRec &ps = pp.paths[(size_t)b * npix + p];
+        out += ps.weight * ld3(ps.L);
+        a += ps.weight;
+    }
+    we[3 * p] = out.x; we[3 * p + 1] = out.y; we[3 * p + 2] = out.z;
+    acc[p] = a;
+    samples[p] += nbatch;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * host runtime
+ * ---------------------------------------------------------------------------------------- */
+static thread_local std::string g_err;
+static int set_err(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(expr)                                                                                            \
+    do {                                                                                                        \
+        hipError_t e_ = (expr);                                                                                 \
+        if (e_ != hipSuccess) return set_err(PTR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+enum { K_RAYGEN = 0, K_TRACE, K_SHADE, K_NEE, K_FILM, K_API_CLOSEST, K_API_OCCLUDED, K_API_RAYGEN };
+static const char *kKernelNames[PTR_PROF_KERNELS] = {"raygen", "trace_closest", "shade", "nee", "film", "api_trace_closest",
+                                                     "api_trace_occluded", "api_generate_rays"};
+
+struct ProfSpan {
+    hipEvent_t a, b;
+    int family;
+    uint64_t items;
+};
+
+struct PtrContext {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::vector<void *> scene_allocs;
+    DScene sc;
+    bool has_scene = false, has_camera = false, has_film = false;
+    bool scene_has_media = false;
+    DCamera cam;
+    int64_t bvh_bytes = 0;
+    /* film */
+    int width = 0, height = 0, npix = 0;
+    uint64_t seed = 0;
+    float *we = nullptr;
+    double *acc = nullptr;
+    long long *samples = nullptr;
+    int sample_cursor = 0, shard_offset = 0, shard_stride = 1;
+    /* pipeline */
+    Pipe pipe;
+    int *queues[3] = {nullptr, nullptr, nullptr};
+    int *counts = nullptr;      /* device: [0] next, [1] nee */
+    int *counts_host = nullptr; /* pinned */
+    int nb_max = 1;
+    unsigned long long *ctrs = nullptr;
+    uint64_t camera_rays = 0;
+    /* profiling */
+    bool profiling = false, count_traversal = false;
+    std::vector<ProfSpan> spans;
+    std::vector<hipEvent_t> event_pool;
+    double prof_ms[PTR_PROF_KERNELS];
+    uint64_t prof_launches[PTR_PROF_KERNELS], prof_items[PTR_PROF_KERNELS];
+};
+
+static int ctx_use(PtrContext *ctx) {
+    if (!ctx) return set_err(PTR_ERR_INVALID, "null context");
+    HIPCHK(hipSetDevice(ctx->device));
+    return PTR_OK;
+}
+
+template <typename T> static int upload(PtrContext *ctx, const T *src, size_t n, const T **out) {
+    *out = nullptr;
+    if (n == 0) return PTR_OK;
+    void *d = nullptr;
+    HIPCHK(hipMalloc(&d, n * sizeof(T)));
+    ctx->scene_allocs.push_back(d);
+    HIPCHK(hipMemcpy(d, src, n * sizeof(T), hipMemcpyHostToDevice));
+    *out = (const T *)d;
+    return PTR_OK;
+}
+static void free_scene(PtrContext *ctx) {
+    for (void *p : ctx->scene_allocs) (void)hipFree(p);
+    ctx->scene_allocs.clear();
+    ctx->has_scene = false;
+}
+static void free_film(PtrContext *ctx) {
+    void *ptrs[] = {ctx->we, ctx->acc, ctx->samples, ctx->pipe.ro, ctx->pipe.rd, ctx->pipe.hprim, ctx->pipe.hface, ctx->pipe.ht,
+                    ctx->pipe.paths, ctx->pipe.nee, ctx->queues[0], ctx->queues[1], ctx->queues[2], ctx->counts};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (ctx->counts_host) (void)hipHostFree(ctx->counts_host);
+    ctx->we = nullptr; ctx->acc = nullptr; ctx->samples = nullptr;
+    memset(&ctx->pipe, 0, sizeof(ctx->pipe));
+    ctx->queues[0] = ctx->queues[1] = ctx->queues[2] = nullptr;
+    ctx->counts = nullptr;
+    ctx->counts_host = nullptr;
+    ctx->has_film = false;
+}
+
+struct ProfScope {
+    PtrContext *ctx;
+    bool on;
+    ProfSpan sp;
+    ProfScope(PtrContext *c, int family, uint64_t items) : ctx(c), on(c->profiling) {
+        if (!on) return;
+        sp.family = family;
+        sp.items = items;
+        for (hipEvent_t *e : {&sp.a, &sp.b}) {
+            if (!ctx->event_pool.empty()) { *e = ctx->event_pool.back(); ctx->event_pool.pop_back(); }
+            else (void)hipEventCreate(e);
+        }
+        (void)hipEventRecord(sp.a, ctx->stream);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(sp.b, ctx->stream);
+        ctx->spans.push_back(sp);
+    }
+};
+static void prof_drain(PtrContext *ctx) {
+    for (ProfSpan &sp : ctx->spans) {
+        (void)hipEventSynchronize(sp.b);
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
+            ctx->prof_ms[sp.family] += ms;
+            ctx->prof_launches[sp.family] += 1;
+            ctx->prof_items[sp.family] += sp.items;
+        }
+        ctx->event_pool.push_back(sp.a);
+        ctx->event_pool.push_back(sp.b);
+    }
+    ctx->spans.clear();
+}
+
+static inline unsigned nblocks(int n) { return (unsigned)((n + TPB - 1) / TPB); }
+
+extern "C" {
+
+const char *ptr_last_error(void) { return g_err.c_str(); }
+
+int ptr_create(int device, PtrContext **out) {
+    if (!out) return set_err(PTR_ERR_INVALID, "null out pointer");
+    *out = nullptr;
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) return set_err(PTR_ERR_HIP, "no HIP device");
+    if (device < 0) HIPCHK(hipGetDevice(&device));
+    if (device >= ndev) return set_err(PTR_ERR_INVALID, "device index out of range");
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (prop.warpSize != 64) return set_err(PTR_ERR_HIP, "device wavefront size is not 64 (built for gfx950)");
+    PtrContext *ctx = new PtrContext();
+    ctx->device = device;
+    memset(&ctx->sc, 0, sizeof(ctx->sc));
+    memset(&ctx->cam, 0, sizeof(ctx->cam));
+    memset(&ctx->pipe, 0, sizeof(ctx->pipe));
+    memset(ctx->prof_ms, 0, sizeof(ctx->prof_ms));
+    memset(ctx->prof_launches, 0, sizeof(ctx->prof_launches));
+    memset(ctx->prof_items, 0, sizeof(ctx->prof_items));
+    if (hipMalloc((void **)&ctx->ctrs, C_COUNT * sizeof(unsigned long long)) != hipSuccess) {
+        delete ctx;
+        return set_err(PTR_ERR_HIP, "hipMalloc(counters) failed");
+    }
+    (void)hipMemset(ctx->ctrs, 0, C_COUNT * sizeof(unsigned long long));
+    *out = ctx;
+    return PTR_OK;
+}
+
+int ptr_destroy(PtrContext *ctx) {
+    if (!ctx) return PTR_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    prof_drain(ctx);
+    for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
+    free_scene(ctx);
+    free_film(ctx);
+    if (ctx->ctrs) (void)hipFree(ctx->ctrs);
+    delete ctx;
+    return PTR_OK;
+}
+
+int ptr_set_stream(PtrContext *ctx, void *hip_stream) {
+    if (!ctx) return set_err(PTR_ERR_INVALID, "null context");
+    ctx->stream = (hipStream_t)hip_stream;
+    return PTR_OK;
+}
+
+int ptr_scene_upload(PtrContext *ctx, const PtrFlatScene *scene) {
+    int rc = ctx_use(ctx);
+    if (rc) return rc;
+    HostScene hs;
+    std::string err;
+    rc = ptr_flatten(scene, &hs, &err);
+    if (rc) return set_err(rc, err);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    free_scene(ctx);
+    DScene sc;
+    memset(&sc, 0, sizeof(sc));
+#define UP(field, vec)                                                      \
+    if ((rc = upload(ctx, (vec).data(), (vec).size(), &sc.field))) return rc;
+    UP(nodes, hs.nodes)
+    UP(items, hs.items)
+    UP(prims, hs.prims)
+    UP(mats, hs.mats)
+    UP(media, hs.media)
+    UP(lights, hs.lights)
+    UP(tris, hs.tris)
+    UP(uvidx, hs.uvidx)
+    UP(env_texels, hs.env_texels)
+    UP(env_func, hs.env_func)
+    UP(env_cdf, hs.env_cdf)
+    UP(env_func_int, hs.env_func_int)
+    UP(env_marg_cdf, hs.env_marg_cdf)
+#undef UP
+    std::vector<DImage> dimg(hs.images.size());
+    for (size_t i = 0; i < hs.images.size(); i++) {
+        if ((rc = upload(ctx, hs.images[i].rgb.data(), hs.images[i].rgb.size(), &dimg[i].rgb))) return rc;
+        dimg[i].width = hs.images[i].w;
+        dimg[i].height = hs.images[i].h;
+    }
+    if ((rc = upload(ctx, dimg.data(), dimg.size(), &sc.images))) return rc;
+    std::vector<DMesh> dmesh(hs.meshes.size());
+    for (size_t i = 0; i < hs.meshes.size(); i++) {
+        dmesh[i].tri_base = hs.meshes[i].tri_base;
+        dmesh[i].n_tris = hs.meshes[i].n_tris;
+        dmesh[i].n_uvs = hs.meshes[i].n_uvs;
+        if ((rc = upload(ctx, hs.meshes[i].uv.data(), hs.meshes[i].uv.size(), &dmesh[i].uv))) return rc;
+    }
+    if ((rc = upload(ctx, dmesh.data(), dmesh.size(), &sc.meshes))) return rc;
+    std::vector<DCloud> dcloud(hs.clouds.size());
+    for (size_t i = 0; i < hs.clouds.size(); i++) {
+        dcloud[i].n = hs.clouds[i].n;
+        dcloud[i].radius = hs.clouds[i].radius;
+        if ((rc = upload(ctx, hs.clouds[i].pos.data(), hs.clouds[i].pos.size(), &dcloud[i].pos))) return rc;
+    }
+    if ((rc = upload(ctx, dcloud.data(), dcloud.size(), &sc.clouds))) return rc;
+    sc.tables = nullptr;
+    sc.env_marg_int = hs.env_marg_int;
+    sc.env_w = hs.env_w; sc.env_h = hs.env_h; sc.env_nu = hs.env_nu; sc.env_nv = hs.env_nv;
+    sc.n_prims = (int)hs.prims.size();
+    sc.n_lights = (int)hs.lights.size();
+    sc.n_nodes = (int)hs.nodes.size();
+    sc.n_items = (int)hs.items.size();
+    sc.view_medium = hs.view_medium;
+    sc.has_env = hs.has_env;
+    ctx->sc = sc;
+    ctx->bvh_bytes = (int64_t)(hs.nodes.size() * sizeof(Node64) + hs.items.size() * sizeof(Item48));
+    ctx->scene_has_media = hs.has_media;
+    ctx->has_scene = true;
+    return PTR_OK;
+}
+
+int ptr_camera_set(PtrContext *ctx, const PtrCamera *cam) {
+    if (!ctx || !cam) return set_err(PTR_ERR_INVALID, "null argument");
+    DCamera c;
+    memcpy(c.position, cam->position, 12);
+    memcpy(c.lower_left, cam->lower_left, 12);
+    memcpy(c.horizontal, cam->horizontal, 12);
+    memcpy(c.vertical, cam->vertical, 12);
+    memcpy(c.u, cam->u, 12);
+    memcpy(c.v, cam->v, 12);
+    memcpy(c.w, cam->w, 12);
+    c.lens_radius = cam->lens_radius;
+    ctx->cam = c;
+    ctx->has_camera = true;
+    return PTR_OK;
+}
+
+int ptr_film_init(PtrContext *ctx, int width, int height, uint64_t seed) {
+    int rc = ctx_use(ctx);
+    if (rc) return rc;
+    if (width <= 0 || height <= 0 || (int64_t)width * height > (1 << 28)) return set_err(PTR_ERR_INVALID, "bad film size");
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    int npix = width * height;
+    if (!ctx->has_film || npix != ctx->npix) {
+        free_film(ctx);
+        int nb = (1 << 22) / npix;
+        if (nb < 1) nb = 1;
+        if (nb > 64) nb = 64;
+        size_t cap = (size_t)npix * nb;
+        if (cap > (size_t)1 << 30) return set_err(PTR_ERR_LIMIT, "film too large for one pass");
+        ctx->nb_max = nb;
+        HIPCHK(hipMalloc((void **)&ctx->we, 3 * sizeof(float) * npix));
+        HIPCHK(hipMalloc((void **)&ctx->acc, sizeof(double) * npix));
+        HIPCHK(hipMalloc((void **)&ctx->samples, sizeof(long long) * npix));
+        HIPCHK(hipMalloc((void **)&ctx->pipe.ro, 3 * sizeof(float) * cap));
+        HIPCHK(hipMalloc((void **)&ctx->pipe.rd, 3 * sizeof(float) * cap));
+        HIPCHK(hipMalloc((void **)&ctx->pipe.hprim, sizeof(int) * cap));
+        HIPCHK(hipMalloc((void **)&ctx->pipe.hface, sizeof(int) * cap));
+        HIPCHK(hipMalloc((void **)&ctx->pipe.ht, sizeof(float) * cap));
+        HIPCHK(hipMalloc((void **)&ctx->pipe.paths, sizeof(PathRec) * cap));
+        HIPCHK(hipMalloc((void **)&ctx->pipe.nee, sizeof(NeeRec) * cap));
+        for (int q = 0; q < 3; q++) HIPCHK(hipMalloc((void **)&ctx->queues[q], sizeof(int) * cap));
+        HIPCHK(hipMalloc((void **)&ctx->counts, 2 * sizeof(int)));
+        HIPCHK(hipHostMalloc((void **)&ctx->counts_host, 2 * sizeof(int), hipHostMallocDefault));
+        ctx->pipe.cap = (int)cap;
+    }
+    ctx->width = width;
+    ctx->height = height;
+    ctx->npix = npix;
+    ctx->seed = seed;
+    ctx->sample_cursor = 0;
+    HIPCHK(hipMemsetAsync(ctx->we, 0, 3 * sizeof(float) * npix, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->acc, 0, sizeof(double) * npix, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->samples, 0, sizeof(long long) * npix, ctx->stream));
+    ctx->has_film = true;
+    return PTR_OK;
+}
+
+int ptr_film_shard(PtrContext *ctx, int sample_offset, int sample_stride) {
+    if (!ctx) return set_err(PTR_ERR_INVALID, "null context");
+    if (sample_stride < 1 || sample_offset < 0 || sample_offset >= sample_stride) return set_err(PTR_ERR_INVALID, "bad shard (offset, stride)");
+    ctx->shard_offset = sample_offset;
+    ctx->shard_stride = sample_stride;
+    return PTR_OK;
+}
+
+/* one pass: nb samples (first, first+step, ...) of every pixel */
+static int run_pass(PtrContext *ctx, int first, int step, int nb, int integrator) {
+    PassParams prm;
+    prm.seed = ctx->seed;
+    prm.npix = ctx->npix;
+    prm.width = ctx->width;
+    prm.height = ctx->height;
+    prm.sample_first = first;
+    prm.sample_step = step;
+    prm.integrator = integrator;
+    hipStream_t s = ctx->stream;
+    const int slots = ctx->npix * nb;
+    {
+        ProfScope ps(ctx, K_RAYGEN, (uint64_t)slots);
+        hipLaunchKernelGGL(k_raygen, dim3(nblocks(slots)), dim3(TPB), 0, s, ctx->sc, ctx->cam, ctx->pipe, prm, slots);
+    }
+    ctx->camera_rays += (uint64_t)slots;
+    int n_cur = slots;
+    const int *q_cur = nullptr; /* identity */
+    int qi = 0;
+    for (int iter = 0; n_cur > 0 && iter < 4096; iter++) {
+        int *q_next = ctx->queues[qi];
+        int *q_nee = ctx->queues[2];
+        HIPCHK(hipMemsetAsync(ctx->counts, 0, 2 * sizeof(int), s));
+        {
+            ProfScope ps(ctx, K_TRACE, (uint64_t)n_cur);
+            if (ctx->count_traversal)
+                hipLaunchKernelGGL(k_trace_closest<true>, dim3(nblocks(n_cur)), dim3(TPB), 0, s, ctx->sc, n_cur, q_cur, ctx->pipe.cap,
+                                   ctx->pipe.ro, ctx->pipe.rd, (const float *)nullptr, ctx->pipe.hprim, ctx->pipe.hface, ctx->pipe.ht,
+                                   (float *)nullptr, (float *)nullptr, ctx->ctrs);
+            else
+                hipLaunchKernelGGL(k_trace_closest<false>, dim3(nblocks(n_cur)), dim3(TPB), 0, s, ctx->sc, n_cur, q_cur, ctx->pipe.cap,
+                                   ctx->pipe.ro, ctx->pipe.rd, (const float *)nullptr, ctx->pipe.hprim, ctx->pipe.hface, ctx->pipe.ht,
+                                   (float *)nullptr, (float *)nullptr, ctx->ctrs);
+        }
+        {
+            ProfScope ps(ctx, K_SHADE, (uint64_t)n_cur);
+            hipLaunchKernelGGL(k_shade, dim3(nblocks(n_cur)), dim3(TPB), 0, s, ctx->sc, ctx->pipe, prm, n_cur, q_cur, q_next, q_nee,
+                               ctx->counts, ctx->ctrs);
+        }
+        HIPCHK(hipMemcpyAsync(ctx->counts_host, ctx->counts, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        int n_next = ctx->counts_host[0], n_nee = ctx->counts_host[1];
+        if (n_nee > 0) {
+            ProfScope ps(ctx, K_NEE, (uint64_t)n_nee);
+            hipLaunchKernelGGL(k_nee, dim3(nblocks(n_nee)), dim3(TPB), 0, s, ctx->sc, ctx->pipe, n_nee, (const int *)q_nee, ctx->ctrs);
+        }
+        q_cur = q_next;
+        n_cur = n_next;
+        qi ^= 1;
+    }
+    {
+        ProfScope ps(ctx, K_FILM, (uint64_t)ctx->npix);
+        hipLaunchKernelGGL(k_film, dim3(nblocks(ctx->npix)), dim3(TPB), 0, s, ctx->pipe, ctx->npix, nb, ctx->we, ctx->acc, ctx->samples);
+    }
+    HIPCHK(hipGetLastError());
+    return PTR_OK;
+}
+
+int ptr_render(PtrContext *ctx, int ns, int integrator) {
+    int rc = ctx_use(ctx);
+    if (rc) return rc;
+    if (!ctx->has_scene || !ctx->has_camera || !ctx->has_film)
+        return set_err(PTR_ERR_STATE, "ptr_render needs ptr_scene_upload, ptr_camera_set and ptr_film_init first");
+    if (ns < 0) return set_err(PTR_ERR_INVALID, "negative sample count");
+    if (integrator < PTR_LI_DIRECT || integrator > PTR_LI_VOLPATH) return set_err(PTR_ERR_INVALID, "unknown integrator");
+    int begin = ctx->sample_cursor, end = begin + ns;
+    ctx->sample_cursor = end;
+    /* first sample index >= begin owned by this shard */
+    int stride = ctx->shard_stride;
+    int first = begin + ((ctx->shard_offset - begin) % stride + stride) % stride;
+    while (first < end) {
+        int remaining = (end - first + stride - 1) / stride;
+        int nb = remaining < ctx->nb_max ? remaining : ctx->nb_max;
+        rc = run_pass(ctx, first, stride, nb, integrator);
+        if (rc) return rc;
+        first += nb * stride;
+    }
+    return PTR_OK;
+}
+
+int ptr_sync(PtrContext *ctx) {
+    int rc = ctx_use(ctx);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipGetLastError());
+    return PTR_OK;
+}
+
+int ptr_film_read(PtrContext *ctx, float *we_rgb, double *acc_weight, int64_t *samples) {
+    int rc = ctx_use(ctx);
+    if (rc) return rc;
+    if (!ctx->has_film) return set_err(PTR_ERR_STATE, "no film");
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (we_rgb) HIPCHK(hipMemcpy(we_rgb, ctx->we, 3 * sizeof(float) * ctx->npix, hipMemcpyDeviceToHost));
+    if (acc_weight) HIPCHK(hipMemcpy(acc_weight, ctx->acc, sizeof(double) * ctx->npix, hipMemcpyDeviceToHost));
+    if (samples) HIPCHK(hipMemcpy(samples, ctx->samples, sizeof(int64_t) * ctx->npix, hipMemcpyDeviceToHost));
+    return PTR_OK;
+}
+
+int ptr_film_device_ptrs(PtrContext *ctx, void **we_rgb, void **acc_weight, void **samples) {
+    if (!ctx) return set_err(PTR_ERR_INVALID, "null context");
+    if (!ctx->has_film) return set_err(PTR_ERR_STATE, "no film");
+    if (we_rgb) *we_rgb = ctx->we;
+    if (acc_weight) *acc_weight = ctx->acc;
+    if (samples) *samples = ctx->samples;
+    return PTR_OK;
+}
+
+int ptr_counters_read(PtrContext *ctx, PtrCounters *out) {
+    int rc = ctx_use(ctx);
+    if (rc) return rc;
+    if (!out) return set_err(PTR_ERR_INVALID, "null out pointer");
+    static_assert(sizeof(PtrCounters) == C_COUNT * sizeof(uint64_t), "counter layout");
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(out, ctx->ctrs, sizeof(PtrCounters), hipMemcpyDeviceToHost));
+    out->camera_rays = ctx->camera_rays;
+    return PTR_OK;
+}
+
+int ptr_counters_reset(PtrContext *ctx) {
+    int rc = ctx_use(ctx);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemset(ctx->ctrs, 0, C_COUNT * sizeof(unsigned long long)));
+    ctx->camera_rays = 0;
+    return PTR_OK;
+}
+
+int ptr_generate_rays(PtrContext *ctx, int sample, float *d_o, float *d_d, float *d_weight) {
+    int rc = ctx_use(ctx);
+    if (rc) return rc;
+    if (!ctx->has_camera || !ctx->has_film) return set_err(PTR_ERR_STATE, "ptr_generate_rays needs a camera and a film");
+    if (!d_o || !d_d) return set_err(PTR_ERR_INVALID, "null ray buffers");
+    PassParams prm;
+    memset(&prm, 0, sizeof(prm));
+    prm.seed = ctx->seed;
+    prm.npix = ctx->npix;
+    prm.width = ctx->width;
+    prm.height = ctx->height;
+    ProfScope ps(ctx, K_API_RAYGEN, (uint64_t)ctx->npix);
+    hipLaunchKernelGGL(k_raygen_only, dim3(nblocks(ctx->npix)), dim3(TPB), 0, ctx->stream, ctx->cam, prm, sample, d_o, d_d, d_weight);
+    HIPCHK(hipGetLastError());
+    return PTR_OK;
+}
+
+int ptr_trace_closest(PtrContext *ctx, int n, const float *d_o, const float *d_d, const float *d_tmax, int32_t *d_prim, int32_t *d_face,
+                      float *d_t, float *d_b0, float *d_b1) {
+    int rc = ctx_use(ctx);
+    if (rc) return rc;
+    if (!ctx->has_scene) return set_err(PTR_ERR_STATE, "no scene uploaded");
+    if (n < 0 || (n > 0 && (!d_o || !d_d || !d_prim || !d_face || !d_t))) return set_err(PTR_ERR_INVALID, "bad ray batch");
+    if (n == 0) return PTR_OK;
+    ProfScope ps(ctx, K_API_CLOSEST, (uint64_t)n);
+    if (ctx->count_traversal)
+        hipLaunchKernelGGL(k_trace_closest<true>, dim3(nblocks(n)), dim3(TPB), 0, ctx->stream, ctx->sc, n, (const int *)nullptr, n, d_o, d_d,
+                           d_tmax, d_prim, d_face, d_t, d_b0, d_b1, ctx->ctrs);
+    else
+        hipLaunchKernelGGL(k_trace_closest<false>, dim3(nblocks(n)), dim3(TPB), 0, ctx->stream, ctx->sc, n, (const int *)nullptr, n, d_o, d_d,
+                           d_tmax, d_prim, d_face, d_t, d_b0, d_b1, ctx->ctrs);
+    HIPCHK(hipGetLastError());
+    return PTR_OK;
+}
+
+int ptr_trace_occluded(PtrContext *ctx, int n, const float *d_o, const float *d_d, const float *d_tmax, int32_t *d_occluded) {
+    int rc = ctx_use(ctx);
+    if (rc) return rc;
+    if (!ctx->has_scene) return set_err(PTR_ERR_STATE, "no scene uploaded");
+    if (n < 0 || (n > 0 && (!d_o || !d_d || !d_occluded))) return set_err(PTR_ERR_INVALID, "bad ray batch");
+    if (n == 0) return PTR_OK;
+    ProfScope ps(ctx, K_API_OCCLUDED, (uint64_t)n);
+    hipLaunchKernelGGL(k_trace_occluded, dim3(nblocks(n)), dim3(TPB), 0, ctx->stream, ctx->sc, n, d_o, d_d, d_tmax, d_occluded);
+    HIPCHK(hipGetLastError());
+    return PTR_OK;
+}
+
+/* on: bit 0 = time every launch with HIP events, bit 1 = count child boxes / leaf items tested */
+int ptr_profile_enable(PtrContext *ctx, int on) {
+    if (!ctx) return set_err(PTR_ERR_INVALID, "null context");
+    ctx->profiling = (on & 1) != 0;
+    ctx->count_traversal = (on & 2) != 0;
+    return PTR_OK;
+}
+int ptr_profile_reset(PtrContext *ctx) {
+    int rc = ctx_use(ctx);
+    if (rc) return rc;
+    prof_drain(ctx);
+    memset(ctx->prof_ms, 0, sizeof(ctx->prof_ms));
+    memset(ctx->prof_launches, 0, sizeof(ctx->prof_launches));
+    memset(ctx->prof_items, 0, sizeof(ctx->prof_items));
+    return PTR_OK;
+}
+int ptr_profile_read(PtrContext *ctx, PtrKernelProfile *out, int max_entries, int *n_out) {
+    int rc = ctx_use(ctx);
+    if (rc) return rc;
+    if (!out || max_entries < 0) return set_err(PTR_ERR_INVALID, "bad profile buffer");
+    prof_drain(ctx);
+    int n = max_entries < PTR_PROF_KERNELS ? max_entries : PTR_PROF_KERNELS;
+    for (int i = 0; i < n; i++) {
+        memset(&out[i], 0, sizeof(out[i]));
+        strncpy(out[i].name, kKernelNames[i], sizeof(out[i].name) - 1);
+        out[i].launches = ctx->prof_launches[i];
+        out[i].total_ms = ctx->prof_ms[i];
+        out[i].items = ctx->prof_items[i];
+    }
+    if (n_out) *n_out = n;
+    return PTR_OK;
+}
+int ptr_bvh_info(PtrContext *ctx, int64_t *n_nodes, int64_t *n_items, int64_t *bytes) {
+    if (!ctx) return set_err(PTR_ERR_INVALID, "null context");
+    if (!ctx->has_scene) return set_err(PTR_ERR_STATE, "no scene uploaded");
+    if (n_nodes) *n_nodes = ctx->sc.n_nodes;
+    if (n_items) *n_items = ctx->sc.n_items;
+    if (bytes) *bytes = ctx->bvh_bytes;
+    return PTR_OK;
+}
+
+} /* extern "C" */

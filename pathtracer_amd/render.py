@@ -1,0 +1,123 @@
+"""Host-side driver of the render path, mirroring the reference's render() sequence
+(src/main.cpp:1092-1157: PrepareSceneForRendering -> SetupPixels -> Render per sample batch ->
+read the Pixel array), every step going through the C-ABI of include/ptr_api.h.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+class Renderer:
+    def __init__(self, device=-1):
+        self._ctx = capi.CTX()
+        capi.check(capi.hip().ptr_create(int(device), C.byref(self._ctx)))
+        self.width = self.height = 0
+
+    # -- lifetime ---------------------------------------------------------------------
+    def close(self):
+        if self._ctx:
+            capi.hip().ptr_destroy(self._ctx)
+            self._ctx = capi.CTX()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def ctx(self):
+        return self._ctx
+
+    def set_stream(self, hip_stream):
+        capi.check(capi.hip().ptr_set_stream(self._ctx, C.c_void_p(int(hip_stream))))
+
+    # -- scene ------------------------------------------------------------------------
+    def upload(self, scene):
+        """scene: BuiltScene / PyScene (anything with a .flat POINTER(PtrFlatScene))."""
+        capi.check(capi.hip().ptr_scene_upload(self._ctx, scene.flat))
+
+    def set_camera(self, cam):
+        capi.check(capi.hip().ptr_camera_set(self._ctx, C.byref(cam)))
+
+    def film_init(self, width, height, seed=1):
+        capi.check(capi.hip().ptr_film_init(self._ctx, int(width), int(height), C.c_uint64(int(seed))))
+        self.width, self.height = int(width), int(height)
+
+    def shard(self, offset, stride):
+        capi.check(capi.hip().ptr_film_shard(self._ctx, int(offset), int(stride)))
+
+    # -- render -----------------------------------------------------------------------
+    def render(self, ns, integrator=capi.LI_VOLPATH):
+        capi.check(capi.hip().ptr_render(self._ctx, int(ns), int(integrator)))
+
+    def sync(self):
+        capi.check(capi.hip().ptr_sync(self._ctx))
+
+    def film(self):
+        """(we[h,w,3] float32, acc_weight[h,w] float64, samples[h,w] int64)"""
+        n = self.width * self.height
+        we = np.empty((n, 3), dtype=np.float32)
+        acc = np.empty(n, dtype=np.float64)
+        smp = np.empty(n, dtype=np.int64)
+        capi.check(capi.hip().ptr_film_read(self._ctx, we.ctypes.data, acc.ctypes.data, smp.ctypes.data))
+        sh = (self.height, self.width)
+        return we.reshape(sh + (3,)), acc.reshape(sh), smp.reshape(sh)
+
+    def film_device_ptrs(self):
+        a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        capi.check(capi.hip().ptr_film_device_ptrs(self._ctx, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def image(self):
+        """GetPixelRGB (camera.cpp:36-51): we / accWeight, NaN -> 0."""
+        we, acc, _ = self.film()
+        with np.errstate(divide="ignore", invalid="ignore"):
+            img = we / acc[..., None].astype(np.float32)
+        img[~np.isfinite(img)] = 0
+        return img
+
+    # -- stages -----------------------------------------------------------------------
+    def generate_rays(self, sample, d_o, d_d, d_weight=None):
+        capi.check(capi.hip().ptr_generate_rays(self._ctx, int(sample), d_o, d_d, d_weight))
+
+    def trace_closest(self, n, d_o, d_d, d_tmax, d_prim, d_face, d_t, d_b0=None, d_b1=None):
+        capi.check(capi.hip().ptr_trace_closest(self._ctx, int(n), d_o, d_d, d_tmax, d_prim, d_face, d_t, d_b0, d_b1))
+
+    def trace_occluded(self, n, d_o, d_d, d_tmax, d_occ):
+        capi.check(capi.hip().ptr_trace_occluded(self._ctx, int(n), d_o, d_d, d_tmax, d_occ))
+
+    # -- introspection ----------------------------------------------------------------
+    def counters(self):
+        c = capi.PtrCounters()
+        capi.check(capi.hip().ptr_counters_read(self._ctx, C.byref(c)))
+        return c.as_dict()
+
+    def counters_reset(self):
+        capi.check(capi.hip().ptr_counters_reset(self._ctx))
+
+    def profile_enable(self, timing=True, count_traversal=False):
+        capi.check(capi.hip().ptr_profile_enable(self._ctx, (1 if timing else 0) | (2 if count_traversal else 0)))
+
+    def profile_reset(self):
+        capi.check(capi.hip().ptr_profile_reset(self._ctx))
+
+    def profile(self):
+        arr = (capi.PtrKernelProfile * capi.PROF_KERNELS)()
+        n = C.c_int(0)
+        capi.check(capi.hip().ptr_profile_read(self._ctx, arr, capi.PROF_KERNELS, C.byref(n)))
+        return {arr[i].name.decode(): {"launches": int(arr[i].launches), "total_ms": float(arr[i].total_ms), "items": int(arr[i].items)}
+                for i in range(n.value)}
+
+    def bvh_info(self):
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        capi.check(capi.hip().ptr_bvh_info(self._ctx, C.byref(a), C.byref(b), C.byref(c)))
+        return {"nodes": a.value, "items": b.value, "bytes": c.value}
