@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the per-ray hot path (BASELINE.json: Mrays/s, incoherent bounces).
+
+Workload at N=1 (BASELINE.json configs[1]): 871,200-triangle torus-knot mesh ("dragon-class"
+stand-in, the author's assets are not available), rough-glass microfacet material, light-map
+sky, 1920x1080, Li_VolPath (the reference's default integrator, main.cpp:447).  One *step* is one
+1-spp pass of the whole image through the wavefront pipeline (raygen -> {trace, shade, nee} per
+bounce -> film); scene, BVH and film are resident in HBM before the timed region starts.
+
+value = (closest-hit + any-hit scene queries of all ranks) / wall time, in Mrays/s.
+N > 1: the scene is replicated, sample indices are dealt round-robin to the ranks (rank r renders
+samples r, r+N, ...: weak scaling), and the float accumulators are summed with one RCCL
+all-reduce inside the timed region.
+
+    python bench.py --gpus 1 --steps 8 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
+
+
+class _DevArray:
+    """Wraps a raw device pointer for torch.as_tensor (CUDA array interface v2)."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def ray_count(c):
+    return c["total_paths"] + c["shadow_rays"] + c["mis_rays"] + c["probe_rays"]
+
+
+def cpu_baseline(scene, width, height, integrator, seed):
+    """The oracle (CPU restatement of the reference path) on this box's host cores, bounded sample."""
+    from oracle import orc
+
+    cores = max(1, min(16, os.cpu_count() or 1))
+    osc = orc.OracleScene(scene.flat, scene.rand_calls)
+    # a reduced-resolution frame of the SAME scene/camera/integrator, sized for ~10-30 s of CPU work
+    w, h = width // 4, height // 4
+    t0 = time.time()
+    osc.render(scene.camera, w, h, seed, 0, 1, integrator, cores)
+    dt = time.time() - t0
+    spp = 1
+    if dt < 8.0:  # extend the sample until it is long enough to time
+        more = int(min(16, max(1, 12.0 / max(dt, 1e-3))))
+        t1 = time.time()
+        osc.render(scene.camera, w, h, seed, 1, more, integrator, cores)
+        dt += time.time() - t1
+        spp += more
+    rays = ray_count(osc.counters())
+    osc.close()
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": "%dx%d x %d spp of the same scene/camera/integrator, %.1f s, %d rays" % (w, h, spp, dt, rays)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--segments", type=int, default=660, help="knot tessellation: 2*s*s triangles (660 -> 871,200)")
+    ap.add_argument("--variant", type=int, default=0, help="0 rough glass, 1 plastic, 2 specular glass, 3 matte")
+    ap.add_argument("--integrator", type=int, default=3)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+
+    import torch
+    import pathtracer_amd as pa
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    W, H = args.width, args.height
+    scene = pa.BuiltScene("knot", W, H, args.segments, args.variant)
+    r = pa.Renderer(local_rank)
+    t_up = time.time()
+    r.upload(scene)
+    t_up = time.time() - t_up
+    r.set_camera(scene.camera)
+    r.film_init(W, H, args.seed)
+    r.shard(rank, world)
+    bvh = r.bvh_info()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        # one 1-spp pass on every rank: `world` consecutive sample indices, one per rank
+        r.render(world, args.integrator)
+
+    for _ in range(args.warmup):
+        step()
+    r.sync()
+
+    # untimed counting pass: child boxes / leaf items tested per traced ray (algorithmic bytes)
+    r.counters_reset()
+    r.profile_enable(timing=False, count_traversal=True)
+    r.profile_reset()
+    step()
+    r.sync()
+    cc = r.counters()
+    r.profile_enable(timing=True, count_traversal=False)
+    r.profile_reset()
+    r.counters_reset()
+    r.film_init(W, H, args.seed)  # the timed region starts from a clean film
+    r.shard(rank, world)
+
+    we_p, acc_p, smp_p = r.film_device_ptrs()
+    we_t = torch.as_tensor(_DevArray(we_p, (H * W * 3,), "<f4"), device=dev)
+    acc_t = torch.as_tensor(_DevArray(acc_p, (H * W,), "<f8"), device=dev)
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    r.sync()
+    if dist is not None:
+        dist.all_reduce(we_t)
+        dist.all_reduce(acc_t)
+    barrier()
+    dt = time.perf_counter() - t0
+
+    c = r.counters()
+    prof = r.profile()
+    rays_local = ray_count(c)
+    stats = torch.tensor([dt, float(rays_local), float(c["camera_rays"])], dtype=torch.float64, device=dev)
+    if dist is not None:
+        tmax = stats[0:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(stats[1:], op=dist.ReduceOp.SUM)
+        stats[0] = tmax[0]
+    dt_max, rays_all, cam_all = [float(v) for v in stats.cpu()]
+
+    if rank == 0:
+        tk = prof["trace_closest"]
+        traced = max(1, cc["total_paths"])
+        nodes_per_ray = cc["nodes_visited"] / traced
+        items_per_ray = cc["prims_tested"] / traced
+        bytes_per_ray = 64.0 + 32.0 * nodes_per_ray + 48.0 * items_per_ray
+        launches = max(1, tk["launches"])
+        avg_ms = tk["total_ms"] / launches
+        rays_per_launch = tk["items"] / launches
+        achieved = bytes_per_ray * rays_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "Mrays/s (incoherent bounces)",
+            "value": rays_all / dt_max / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt_max * 1e3 / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: %d-triangle torus-knot mesh (dragon-class stand-in), %s, light-map sky, %dx%d, "
+                                   "1 spp per step per GPU, integrator %d (Li_VolPath=3)" %
+                                   (2 * args.segments * args.segments, ["rough glass (microfacet)", "plastic", "specular glass", "matte"][args.variant],
+                                    W, H, args.integrator),
+                       "triangles": 2 * args.segments * args.segments, "width": W, "height": H,
+                       "bvh_nodes": bvh["nodes"], "bvh_items": bvh["items"], "bvh_bytes": bvh["bytes"],
+                       "scene_upload_s": round(t_up, 3), "parallelism": "samples round-robin over %d GPU(s), scene replicated" % world},
+            "samples_per_s": cam_all / dt_max,
+            "rays_per_sample": rays_all / max(1.0, cam_all),
+            "roofline": {"bound": "hbm", "kernel": "k_trace_closest", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "bytes_per_ray": bytes_per_ray, "nodes_per_ray": nodes_per_ray, "items_per_ray": items_per_ray,
+                         "avg_launch_ms": avg_ms, "rays_per_launch": rays_per_launch, "launches": tk["launches"]},
+            "kernels_ms": {k: round(v["total_ms"], 3) for k, v in prof.items() if v["launches"]},
+        }
+        if not args.no_cpu and world == 1:
+            out["cpu_baseline"] = cpu_baseline(scene, W, H, args.integrator, args.seed)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    r.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

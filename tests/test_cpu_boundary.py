@@ -1,0 +1,149 @@
+"""CPU-side checks of the boundary: the C-ABI library loads and exports every symbol
+include/ptr_api.h declares (no compute calls: there is no GPU here), the ctypes mirror of the
+structs has the C layout, the host-side scene mirror produces consistent flat scenes."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import pathtracer_amd as pa
+from pathtracer_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "ptr_api.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ptr_[a-z_]+)\s*\(", src)))
+
+
+def test_header_declares_expected_entry_points():
+    names = declared_functions()
+    assert len(names) >= 20
+    assert set(names) == set(capi.HIP_SIGNATURES)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = capi.hip()
+    for name in declared_functions():
+        assert getattr(lib, name) is not None
+    out = subprocess.run(["nm", "-D", "--defined-only", capi.HIP_LIB], stdout=subprocess.PIPE, text=True, check=True).stdout
+    exported = set(re.findall(r" T (ptr_[a-z_]+)", out))
+    assert set(declared_functions()) <= exported
+
+
+def test_every_declaration_cites_the_reference():
+    """each entry point's comment names the reference file:line it replaces (or says it has none)"""
+    src = open(HEADER).read()
+    for name in declared_functions():
+        pos = src.index(name + "(")
+        comment = src[:pos].rsplit("/*", 1)[1] if "/*" in src[:pos] else ""
+        block = src[max(0, pos - 1500):pos]
+        assert re.search(r"\.(cpp|h):\d+", block) or "no counterpart" in block.lower() or "No counterpart" in block, name
+
+
+def test_struct_layout_matches_c(tmp_path):
+    """sizeof of every boundary struct, as a C compiler sees the header vs the ctypes mirror"""
+    names = ["PtrTransform", "PtrTexture", "PtrMaterial", "PtrMedium", "PtrPrimitive", "PtrMesh", "PtrCloud", "PtrImage",
+             "PtrEnvMap", "PtrFlatScene", "PtrCamera", "PtrCounters", "PtrKernelProfile"]
+    prog = '#include <stdio.h>\n#include "ptr_api.h"\nint main(){' + "".join('printf("%%zu\\n", sizeof(%s));' % n for n in names) + "return 0;}"
+    c = tmp_path / "sz.c"
+    c.write_text(prog)
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)], check=True)
+    sizes = [int(x) for x in subprocess.run([str(exe)], stdout=subprocess.PIPE, text=True, check=True).stdout.split()]
+    for n, s in zip(names, sizes):
+        assert C.sizeof(getattr(capi, n)) == s, n
+
+
+def test_no_fallback_when_library_missing(monkeypatch):
+    monkeypatch.setattr(capi, "_hip", None)
+    monkeypatch.setattr(capi, "HIP_LIB", "/nonexistent/libptr_hip.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        capi.hip()
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "pathtracer_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle/" not in text and "liborc" not in text and "from oracle" not in text and "orc_" not in text, f
+
+
+def mat4(t):
+    return np.array(list(t.m), np.float64).reshape(4, 4), np.array(list(t.mInv), np.float64).reshape(4, 4)
+
+
+@pytest.mark.parametrize("kind,args", [("translate", (1, -2, 3, 0)), ("scale", (2, 3, 0.5, 0)), ("rotx", (30, 0, 0, 0)),
+                                       ("roty", (-75, 0, 0, 0)), ("rotz", (110, 0, 0, 0)), ("rotate", (40, 1, 2, 3)), ("trs", (1, 2, 3, 25))])
+def test_transform_factories(kind, args):
+    """Translate/Scale/Rotate* (transform.cpp:92-197): m * mInv = I and the expected matrices"""
+    t = capi.PtrTransform()
+    capi.host().pth_transform(kind.encode(), *[float(a) for a in args], C.byref(t))
+    m, mi = mat4(t)
+    assert np.allclose(m @ mi, np.eye(4), atol=2e-6)
+    if kind == "translate":
+        assert np.allclose(m[:3, 3], args[:3]) and np.allclose(m[:3, :3], np.eye(3))
+    if kind == "roty":
+        a = np.radians(args[0])
+        assert np.allclose(m[:3, :3], [[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], atol=1e-6)
+    if kind == "rotate":
+        axis = np.array(args[1:], np.float64)
+        axis /= np.linalg.norm(axis)
+        assert np.allclose(m[:3, :3] @ axis, axis, atol=1e-6) and np.isclose(np.linalg.det(m[:3, :3]), 1, atol=1e-5)
+
+
+def test_camera_config_pinhole():
+    """Camera::Config (camera.cpp:145-173): the frustum corners follow from eye/at/up/fov"""
+    eye, at, up = np.array([0, 4, -25.0]), np.array([0, 4, 0.0]), np.array([0, 1, 0.0])
+    cam = pa.look_at_camera(eye, at, up, 40, 1.5)
+    pos, ll = np.array(list(cam.position)), np.array(list(cam.lower_left))
+    hor, ver = np.array(list(cam.horizontal)), np.array(list(cam.vertical))
+    assert np.allclose(pos, eye) and cam.lens_radius == 0
+    centre = ll + 0.5 * hor + 0.5 * ver - pos
+    assert np.allclose(centre / np.linalg.norm(centre), (at - eye) / np.linalg.norm(at - eye), atol=1e-6)
+    assert np.isclose(np.linalg.norm(hor) / np.linalg.norm(ver), 1.5, rtol=1e-5)
+    half_h = np.tan(np.radians(40) / 2)
+    assert np.isclose(np.linalg.norm(ver) / 2 / np.linalg.norm(centre), half_h, rtol=1e-5)
+    assert abs(hor @ ver) < 1e-5
+
+
+def test_flat_scenes_are_consistent():
+    for fam, p0, p1 in [("cornell", 0, 3), ("knot", 16, 0), ("zoo", 0, 3), ("volcaustic", 0, 0), ("fluid", 500, 0), ("subsurface", 8, 0)]:
+        sc = pa.BuiltScene(fam, 64, 48, p0, p1)
+        fs = sc.flat.contents
+        assert fs.n_primitives > 0
+        for i in range(fs.n_primitives):
+            p = fs.primitives[i]
+            assert 0 <= p.shape_type <= 8
+            m, mi = mat4(p.to_world)
+            assert np.allclose(m @ mi, np.eye(4), atol=1e-4)
+            if p.shape_type == capi.SHAPE_MESH:
+                assert 0 <= p.geom < fs.n_meshes
+            if p.shape_type == capi.SHAPE_PARTICLECLOUD:
+                assert 0 <= p.geom < fs.n_clouds
+        for i in range(fs.n_meshes):
+            me = fs.meshes[i]
+            idx = np.ctypeslib.as_array(me.indices, shape=(me.n_triangles * 9,)).reshape(-1, 3, 3)
+            assert idx[:, :, 0].min() >= 0 and idx[:, :, 0].max() < me.n_vertices
+        if fs.has_envmap:
+            e = fs.envmap
+            assert e.nu == 2 * e.width and e.nv == 2 * e.height
+            cdf = np.ctypeslib.as_array(e.marg_cdf, shape=(e.nv + 1,))
+            assert cdf[0] == 0 and np.isclose(cdf[-1], 1) and np.all(np.diff(cdf) >= 0)
+            rows = np.ctypeslib.as_array(e.cdf, shape=(e.nv, e.nu + 1))
+            assert np.allclose(rows[:, -1], 1) and np.all(np.diff(rows, axis=1) >= 0)
+        sc.close()
+
+
+def test_knot_mesh_size_of_config_2():
+    sc = pa.BuiltScene("knot", 64, 48, 660, 0)
+    assert sc.flat.contents.meshes[0].n_triangles == 871200
+    sc.close()
