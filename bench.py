@@ -44,18 +44,15 @@ def cpu_baseline(scene, width, height, integrator, seed):
 
     cores = max(1, min(16, os.cpu_count() or 1))
     osc = orc.OracleScene(scene.flat, scene.rand_calls)
-    # a reduced-resolution frame of the SAME scene/camera/integrator, sized for ~10-30 s of CPU work
-    w, h = width // 4, height // 4
-    t0 = time.time()
-    osc.render(scene.camera, w, h, seed, 0, 1, integrator, cores)
-    dt = time.time() - t0
-    spp = 1
-    if dt < 8.0:  # extend the sample until it is long enough to time
-        more = int(min(16, max(1, 12.0 / max(dt, 1e-3))))
-        t1 = time.time()
-        osc.render(scene.camera, w, h, seed, 1, more, integrator, cores)
-        dt += time.time() - t1
-        spp += more
+    # a reduced-resolution frame of the SAME scene/camera/integrator, repeated until ~12 s of CPU work
+    w, h = width // 2, height // 2
+    dt, spp = 0.0, 0
+    while dt < 12.0 and spp < 512:
+        ns = 1 if spp == 0 else int(min(64, max(1, (12.5 - dt) / max(dt / spp, 1e-3))))
+        t0 = time.time()
+        osc.render(scene.camera, w, h, seed, spp, ns, integrator, cores)
+        dt += time.time() - t0
+        spp += ns
     rays = ray_count(osc.counters())
     osc.close()
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",

@@ -76,7 +76,7 @@ static int CreateBVHRec(BVH &bvh, PrimitiveHandle *handles, int n, int depth, in
     int axis = int(3 * rng.rand_float());
     if (axis != last_axis) {
         last_axis = axis;
-        QuickSortHandles(handles, n, axis);
+        if (axis <= 2) QuickSortHandles(handles, n, axis); /* rand_float() can round to 1.0f: axis 3 sorts nothing */
     }
     if (n == 1 || depth >= max_depth) {
         bvh.nodes[me].handles = (int)bvh.handles.size();

@@ -226,12 +226,9 @@ PD bool proc_hit_t(const DPrim &pr, const f3 &ro, const f3 &rd, float rtmax, flo
     return hit;
 }
 
-/* per-primitive dispatch used at PRIM leaves: reference leaf-node box test (the leaf's box is the
- * primitive's own GetBounds(), primitive.cpp:386-390,557-563) followed by Shape::Intersect */
-PD bool prim_hit_t(const DScene &sc, int prim, const f3 &ro, const f3 &rd, const f3 &inv, float tmax, float *tHit, int *face) {
-    const DPrim &pr = sc.prims[prim];
-    float te;
-    if (!slab_test(pr.bmin, pr.bmax, ro, inv, tmax, &te)) return false;
+/* Shape::Intersect of an analytic primitive: hit distance only (the interaction is rebuilt by
+ * make_si for the one hit that survives) */
+PD bool shape_hit_t(const DPrim &pr, const f3 &ro, const f3 &rd, float tmax, float *tHit, int *face) {
     *face = 0;
     switch (pr.type) {
     case SH_SPHERE: {
@@ -246,22 +243,30 @@ PD bool prim_hit_t(const DScene &sc, int prim, const f3 &ro, const f3 &rd, const
     }
 }
 
-/* ---- BVH traversal (replaces primitive.cpp:374-431 + the nested loops of mesh.cpp:454-509 and
- * particlecloud.cpp:197-274 with ONE loop over a unified, SAH-built, 64-byte-node BVH) ---------
- * Closest hit: the reference accepts t <= tMax, so later equal-t candidates replace earlier ones;
- * which one is "later" depends on its BVH — ties are reported by the oracle and excluded from
- * exact comparison.  ANY = true returns at the first hit. */
+/* ---- traversal -------------------------------------------------------------------------------
+ * Two levels, as in the reference, but laid out differently:
+ *
+ *  top   the reference's own median-split BVH over primitives (tens of nodes), walked exactly as
+ *        Aggregator::Intersect walks it (primitive.cpp:374-431): a few answers depend on the
+ *        order in which primitives are met (an SDF hit distance is measured along the normalised
+ *        direction and can inflate tMax of a non-unit shadow ray, procedural.cpp:238; a
+ *        rectangle's hit can lie in front of its bounds, rectangle.cpp:8 vs :37-40).
+ *  geom  meshes and particle clouds: one SAH-built BVH each, 64-byte nodes carrying both
+ *        children's boxes, 48-byte pre-gathered leaf records, near child first (replaces the
+ *        nested loops of mesh.cpp:454-509 and particlecloud.cpp:197-274).
+ *
+ * Closest hit: the reference accepts t <= tMax, so of two hits at bit-equal t the later tested
+ * wins; inside a mesh that depends on its BVH - the oracle reports such rays and the tests
+ * exclude them.  ANY = true returns at the first accepted hit. */
 struct TraceStats { unsigned nodes, items; };
 
 template <bool ANY, bool COUNT>
-PD bool traverse(const DScene &sc, const f3 &ro, const f3 &rd, float &tmax, int &hprim, int &hface, float &hb0, float &hb1,
-                 TraceStats *st) {
+PD bool bvh_closest(const DScene &sc, int root, const f3 &ro, const f3 &rd, const f3 &inv, float &tmax, int &hface, float &hb0,
+                    float &hb1, TraceStats *st) {
     int stack[BVH_STACK];
     int sp = 0;
-    f3 inv(1 / rd.x, 1 / rd.y, 1 / rd.z);
     bool hit = false;
-    int node = 0;
-    if (sc.n_nodes == 0) return false;
+    int node = root;
     while (true) {
         if (node >= 0) {
             const float4 *np = reinterpret_cast<const float4 *>(sc.nodes + node);
@@ -270,8 +275,8 @@ PD bool traverse(const DScene &sc, const f3 &ro, const f3 &rd, float &tmax, int 
             float rmin[3] = {b.z, b.w, c.x}, rmax[3] = {c.y, c.z, c.w};
             int left = __float_as_int(d.x), right = __float_as_int(d.y);
             float tl, tr;
-            bool hl = (left != BVH_NO_CHILD) && slab_test(lmin, lmax, ro, inv, tmax, &tl);
-            bool hr = (right != BVH_NO_CHILD) && slab_test(rmin, rmax, ro, inv, tmax, &tr);
+            bool hl = slab_test(lmin, lmax, ro, inv, tmax, &tl);
+            bool hr = slab_test(rmin, rmax, ro, inv, tmax, &tr);
             if (COUNT) st->nodes += 2;
             if (hl && hr) {
                 int first = left, second = right;
@@ -288,27 +293,19 @@ PD bool traverse(const DScene &sc, const f3 &ro, const f3 &rd, float &tmax, int 
                 const float4 *ip = reinterpret_cast<const float4 *>(sc.items + first + i);
                 float4 q0 = ip[0], q1 = ip[1], q2 = ip[2];
                 int kind = __float_as_int(q2.w);
-                int prim = __float_as_int(q0.w);
                 if (COUNT) st->items += 1;
                 if (kind == ITEM_TRI) {
                     float t, b0, b1, b2;
                     if (tri_hit(ro, rd, tmax, f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), &t, &b0, &b1, &b2)) {
-                        tmax = t; hprim = prim; hface = __float_as_int(q1.w); hb0 = b0; hb1 = b1; hit = true;
+                        tmax = t; hface = __float_as_int(q1.w); hb0 = b0; hb1 = b1; hit = true;
                         if (ANY) return true;
                     }
-                } else if (kind == ITEM_PARTICLE) {
+                } else {
                     f3 o, d;
                     particle_object_ray(ro, rd, f3(q0.x, q0.y, q0.z), &o, &d);
                     float t;
                     if (sphere_hit_t_obj(o, d, q1.x, tmax, &t)) {
-                        tmax = t; hprim = prim; hface = __float_as_int(q1.w); hb0 = 0; hb1 = 0; hit = true;
-                        if (ANY) return true;
-                    }
-                } else {
-                    float t;
-                    int face;
-                    if (prim_hit_t(sc, prim, ro, rd, inv, tmax, &t, &face)) {
-                        tmax = t; hprim = prim; hface = face; hb0 = 0; hb1 = 0; hit = true;
+                        tmax = t; hface = __float_as_int(q1.w); hb0 = 0; hb1 = 0; hit = true;
                         if (ANY) return true;
                     }
                 }
@@ -316,6 +313,73 @@ PD bool traverse(const DScene &sc, const f3 &ro, const f3 &rd, float &tmax, int 
         }
         if (sp == 0) break;
         node = stack[--sp];
+    }
+    return hit;
+}
+
+/* PrimitiveIntersect (primitive.cpp:52-73) for the primitive of a top-level leaf */
+template <bool ANY, bool COUNT>
+PD bool prim_closest(const DScene &sc, int p, const f3 &ro, const f3 &rd, const f3 &inv, float &tmax, int &hprim, int &hface,
+                     float &hb0, float &hb1, TraceStats *st) {
+    const DPrim &pr = sc.prims[p];
+    if (pr.type == SH_MESH || pr.type == SH_CLOUD) {
+        /* Mesh::Intersect / ParticleCloud::Intersect start with their own root box, which is
+         * the primitive's bound the leaf just passed: go straight to the geometry BVH */
+        if (bvh_closest<ANY, COUNT>(sc, pr.root, ro, rd, inv, tmax, hface, hb0, hb1, st)) { hprim = p; return true; }
+        return false;
+    }
+    float t;
+    int face;
+    if (COUNT) st->items += 1;
+    if (shape_hit_t(pr, ro, rd, tmax, &t, &face)) {
+        tmax = t; hprim = p; hface = face; hb0 = 0; hb1 = 0;
+        return true;
+    }
+    return false;
+}
+
+/* Aggregator::Intersect, primitive.cpp:374-431, step for step over the reference's own tree */
+template <bool ANY, bool COUNT>
+PD bool traverse(const DScene &sc, const f3 &ro, const f3 &rd, float &tmax, int &hprim, int &hface, float &hb0, float &hb1,
+                 TraceStats *st) {
+    if (sc.n_top == 0) return false;
+    f3 inv(1 / rd.x, 1 / rd.y, 1 / rd.z);
+    bool hit = false;
+    int stack[TOP_STACK];
+    int sp = 0;
+    stack[sp++] = -1;
+    int node = 0;
+    while (node != -1) {
+        const TopNode &nd = sc.top[node];
+        float te;
+        if (COUNT) st->nodes += 1;
+        if (slab_test(nd.bmin, nd.bmax, ro, inv, tmax, &te)) {
+            if (nd.left < 0) {
+                for (int i = 0; i < nd.n; i++) {
+                    if (prim_closest<ANY, COUNT>(sc, sc.order[nd.first + i], ro, rd, inv, tmax, hprim, hface, hb0, hb1, st)) {
+                        hit = true;
+                        if (ANY) return true;
+                    }
+                }
+                node = stack[--sp];
+            } else {
+                const TopNode &l = sc.top[nd.left];
+                const TopNode &r = sc.top[nd.right];
+                float tl0, tr0;
+                if (COUNT) st->nodes += 2;
+                bool visitL = slab_test(l.bmin, l.bmax, ro, inv, tmax, &tl0);
+                bool visitR = slab_test(r.bmin, r.bmax, ro, inv, tmax, &tr0);
+                if (visitR && visitL) {
+                    int first, second;
+                    if (tr0 < tl0) { first = nd.right; second = nd.left; }
+                    else { first = nd.left; second = nd.right; }
+                    if (sp < TOP_STACK) stack[sp++] = second;
+                    node = first;
+                } else if (visitL) node = nd.left;
+                else if (visitR) node = nd.right;
+                else node = stack[--sp];
+            }
+        } else node = stack[--sp];
     }
     return hit;
 }

@@ -211,29 +211,13 @@ PD void shape_sample_ref(const DScene &sc, int prim, const Ref &ref, const f2 &u
     }
 }
 
-/* Shape::Intersect of one primitive, no bounds pre-test (Shape::Pdf path, sphere.cpp:3-14) */
-PD bool shape_hit(const DScene &sc, int prim, const f3 &ro, const f3 &rd, float *tHit, int *face) {
-    const DPrim &pr = sc.prims[prim];
-    *face = 0;
-    switch (pr.type) {
-    case SH_SPHERE: {
-        f3 o, d;
-        xf_ray_err(pr.w2o, ro, rd, &o, &d);
-        return sphere_hit_t_obj(o, d, pr.p[0], kInfinity, tHit);
-    }
-    case SH_RECT: return rect_hit_t(pr, ro, rd, kInfinity, tHit);
-    case SH_DISK: return disk_hit_t(pr, ro, rd, kInfinity, tHit);
-    case SH_SPHERE_PROC: case SH_BOX_PROC: case SH_TOY: return proc_hit_t(pr, ro, rd, kInfinity, tHit, face);
-    default: return false;
-    }
-}
 PD f3 spawn_origin(const Ref &r, const f3 &d) { return offset_ray_origin(r.p, r.pError, r.n, d); }
 
 PD float shape_pdf_generic(const DScene &sc, int prim, const Ref &ref, const f3 &wi) {
     f3 ro = spawn_origin(ref, wi);
     float t;
     int face;
-    if (!shape_hit(sc, prim, ro, wi, &t, &face)) return 0;
+    if (!shape_hit_t(sc.prims[prim], ro, wi, kInfinity, &t, &face)) return 0; /* Shape::Pdf, sphere.cpp:3-14 */
     SI li;
     make_si(sc, prim, face, ro, wi, t, -1, &li);
     float f = (absdot(li.n, -wi) * sc.prims[prim].area);

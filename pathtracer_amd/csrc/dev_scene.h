@@ -20,6 +20,17 @@ struct Node64 {
     int32_t left, right;
     int32_t pad[2];
 };
+/* Node of the top-level BVH over primitives: the reference's own tree (primitive.cpp:537-582),
+ * kept because a few results depend on its visiting order.  Leaf: left = -1, handles
+ * order[first .. first+n). */
+struct TopNode {
+    float bmin[3];
+    int32_t left;
+    float bmax[3];
+    int32_t right;
+    int32_t first, n, pad[2];
+};
+#define TOP_STACK 48
 #define BVH_NO_CHILD INT32_MIN
 #define BVH_MAX_LEAF 4
 #define BVH_STACK 64
@@ -42,6 +53,7 @@ struct DPrim {
                                toy: bounds pMin xyz, pMax xyz | cloud: radius */
     float L[3];
     float area; /* Shape::Area() (unused for meshes: their sampling works per triangle) */
+    int32_t root; /* mesh / cloud: root ref of its BVH (node index, or a leaf ref if < 0) */
 };
 
 struct DTex {
@@ -96,12 +108,15 @@ struct DScene {
     const DTable *tables;
     const float *tris;     /* 9 floats / triangle, original order, world space */
     const int32_t *uvidx;  /* 3 ints / triangle */
+    const TopNode *top;    /* the reference's BVH over primitives, root = 0 */
+    const int32_t *order;  /* its leaf handles: primitive indices */
     /* environment map */
     const float *env_texels, *env_func, *env_cdf, *env_func_int, *env_marg_cdf;
     float env_marg_int;
     int32_t env_w, env_h, env_nu, env_nv;
     int32_t n_prims, n_lights, n_nodes, n_items;
     int32_t view_medium, has_env;
+    int32_t n_top;
 };
 
 struct DCamera {

@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace {
@@ -85,9 +86,11 @@ struct Builder {
     std::vector<Node64> nodes;
     std::vector<uint32_t> order;
     int max_depth = 0;
+    int32_t node_base = 0;
+    uint32_t item_base = 0;
     static const int NB = 32;
 
-    explicit Builder(const std::vector<Box> &b) : boxes(b) {
+    Builder(const std::vector<Box> &b, size_t nbase, size_t ibase) : boxes(b), node_base((int32_t)nbase), item_base((uint32_t)ibase) {
         idx.resize(b.size());
         cen.resize(3 * b.size());
         for (size_t i = 0; i < b.size(); i++) {
@@ -96,7 +99,7 @@ struct Builder {
         }
     }
     int32_t make_leaf(size_t lo, size_t hi) {
-        uint32_t first = (uint32_t)order.size(), n = (uint32_t)(hi - lo);
+        uint32_t first = item_base + (uint32_t)order.size(), n = (uint32_t)(hi - lo);
         for (size_t i = lo; i < hi; i++) order.push_back(idx[i]);
         uint32_t packed = first | ((n - 1) << 27);
         return -(int32_t)packed - 1;
@@ -185,6 +188,7 @@ struct Builder {
         }
         int32_t me = (int32_t)nodes.size();
         nodes.emplace_back();
+        const int32_t me_global = node_base + me;
         Box lb, rb;
         int32_t l = build(lo, mid, &lb, depth + 1);
         int32_t r = build(mid, hi, &rb, depth + 1);
@@ -193,9 +197,86 @@ struct Builder {
         nd.left = l;
         nd.right = r;
         nd.pad[0] = nd.pad[1] = 0;
-        return me;
+        return me_global;
     }
 };
+
+/* ---- the reference's top-level visiting order ------------------------------------------ */
+inline float host_rand_float() { return rand() / 2147483648.f; } /* util.h:64-66: rand() / (RAND_MAX + 1.f) */
+struct TopHandle {
+    float pmin[3], pmax[3];
+    int32_t prim;
+};
+/* util.h:10-39 with CompareX/Y/Z (a.bound.pMin[axis] >= b.bound.pMin[axis]) */
+void sort_handles(TopHandle *arr, int elements, int axis) {
+    const int MAX_LEVELS = 1000;
+    int beg[MAX_LEVELS], end[MAX_LEVELS], i = 0;
+    beg[0] = 0;
+    end[0] = elements;
+    while (i >= 0) {
+        int L = beg[i], R = end[i] - 1;
+        if (L < R) {
+            TopHandle piv = arr[L];
+            if (i == MAX_LEVELS - 1) return;
+            while (L < R) {
+                while (arr[R].pmin[axis] >= piv.pmin[axis] && L < R) R--;
+                if (L < R) arr[L++] = arr[R];
+                while (piv.pmin[axis] >= arr[L].pmin[axis] && L < R) L++;
+                if (L < R) arr[R--] = arr[L];
+            }
+            arr[L] = piv;
+            beg[i + 1] = L + 1;
+            end[i + 1] = end[i];
+            end[i++] = L;
+        } else i--;
+    }
+}
+/* _CreateBVH (primitive.cpp:537-582) over the primitives: median split, sort axis from rand(),
+ * sort skipped when the axis repeats; rand_float() can round to 1.0f, axis 3 sorts nothing */
+int build_top(std::vector<TopNode> &nodes, std::vector<int32_t> &order, TopHandle *h, int n, int depth, int max_depth, int last_axis) {
+    int me = (int)nodes.size();
+    nodes.emplace_back();
+    int axis = int(3 * host_rand_float());
+    if (axis != last_axis) {
+        last_axis = axis;
+        if (axis >= 0 && axis <= 2) sort_handles(h, n, axis);
+    }
+    TopNode nd;
+    memset(&nd, 0, sizeof(nd));
+    if (n == 1 || depth >= max_depth) {
+        nd.left = nd.right = -1;
+        nd.first = (int32_t)order.size();
+        nd.n = n;
+        for (int a = 0; a < 3; a++) { nd.bmin[a] = h[0].pmin[a]; nd.bmax[a] = h[0].pmax[a]; }
+        for (int i = 0; i < n; i++) {
+            order.push_back(h[i].prim);
+            for (int a = 0; a < 3; a++) {
+                if (h[i].pmin[a] < nd.bmin[a]) nd.bmin[a] = h[i].pmin[a];
+                if (h[i].pmax[a] > nd.bmax[a]) nd.bmax[a] = h[i].pmax[a];
+            }
+        }
+        nodes[me] = nd;
+        return me;
+    }
+    int l = build_top(nodes, order, h, n / 2, depth + 1, max_depth, last_axis);
+    int r = build_top(nodes, order, h + n / 2, n - n / 2, depth + 1, max_depth, last_axis);
+    nd.left = l;
+    nd.right = r;
+    for (int a = 0; a < 3; a++) {
+        nd.bmin[a] = nodes[l].bmin[a] < nodes[r].bmin[a] ? nodes[l].bmin[a] : nodes[r].bmin[a];
+        nd.bmax[a] = nodes[l].bmax[a] > nodes[r].bmax[a] ? nodes[l].bmax[a] : nodes[r].bmax[a];
+    }
+    nodes[me] = nd;
+    return me;
+}
+/* the rand() draws of one _CreateBVH over n handles: one per node */
+void burn_bvh_rand(int n, int depth, int max_depth) {
+    if (n <= 0) return;
+    (void)rand();
+    if (n == 1 || depth >= max_depth) return;
+    burn_bvh_rand(n / 2, depth + 1, max_depth);
+    burn_bvh_rand(n - n / 2, depth + 1, max_depth);
+}
 
 int fail(std::string *err, int code, const std::string &msg) {
     if (err) *err = msg;
@@ -262,14 +343,72 @@ int ptr_flatten(const PtrFlatScene *fs, HostScene *hs, std::string *err) {
         hs->clouds.push_back(std::move(hc));
     }
 
+    /* one SAH BVH per mesh and per particle cloud, all in the same node / item arrays */
+    std::vector<int32_t> mesh_root(hs->meshes.size(), BVH_NO_CHILD), cloud_root(hs->clouds.size(), BVH_NO_CHILD);
+    std::vector<Box> mesh_box(hs->meshes.size()), cloud_box(hs->clouds.size());
+    auto build_geom = [&](const std::vector<Box> &boxes, const std::vector<Item48> &raw, int32_t *root, Box *bound) -> int {
+        if (boxes.empty()) return PTR_OK;
+        if (hs->items.size() + boxes.size() >= (1u << 27)) return fail(err, PTR_ERR_LIMIT, "more than 2^27 BVH items");
+        Builder b(boxes, hs->nodes.size(), hs->items.size());
+        b.nodes.reserve(boxes.size());
+        b.order.reserve(boxes.size());
+        *root = b.build(0, boxes.size(), bound, 0);
+        if (b.max_depth + 2 > BVH_STACK) return fail(err, PTR_ERR_LIMIT, "BVH deeper than the traversal stack");
+        if (b.max_depth > hs->bvh_depth) hs->bvh_depth = b.max_depth;
+        hs->nodes.insert(hs->nodes.end(), b.nodes.begin(), b.nodes.end());
+        for (size_t i = 0; i < b.order.size(); i++) hs->items.push_back(raw[b.order[i]]);
+        return PTR_OK;
+    };
+    for (size_t mi = 0; mi < hs->meshes.size(); mi++) {
+        const HostMesh &hm = hs->meshes[mi];
+        std::vector<Box> boxes(hm.n_tris);
+        std::vector<Item48> raw(hm.n_tris);
+        for (int t = 0; t < hm.n_tris; t++) { /* MeshGetBounds, mesh.cpp:609-626 */
+            const float *v = &hs->tris[9 * (size_t)(hm.tri_base + t)];
+            Box tb;
+            tb.reset();
+            tb.grow(v);
+            tb.grow(v + 3);
+            tb.grow(v + 6);
+            Item48 it;
+            it.q[0] = v[0]; it.q[1] = v[1]; it.q[2] = v[2]; it.q[3] = 0;
+            it.q[4] = v[3]; it.q[5] = v[4]; it.q[6] = v[5]; it.q[7] = as_float(t);
+            it.q[8] = v[6]; it.q[9] = v[7]; it.q[10] = v[8]; it.q[11] = as_float(ITEM_TRI);
+            boxes[t] = tb;
+            raw[t] = it;
+        }
+        int rc = build_geom(boxes, raw, &mesh_root[mi], &mesh_box[mi]);
+        if (rc) return rc;
+    }
+    for (size_t ci = 0; ci < hs->clouds.size(); ci++) {
+        const HostCloud &c = hs->clouds[ci];
+        std::vector<Box> boxes(c.n);
+        std::vector<Item48> raw(c.n);
+        for (int k = 0; k < c.n; k++) { /* ParticleCloudGetBounds, particlecloud.cpp:284-293 */
+            Box tb;
+            for (int a = 0; a < 3; a++) {
+                tb.mn[a] = -c.radius + c.pos[3 * (size_t)k + a];
+                tb.mx[a] = c.radius + c.pos[3 * (size_t)k + a];
+            }
+            Item48 it;
+            memset(&it, 0, sizeof(it));
+            it.q[0] = c.pos[3 * (size_t)k]; it.q[1] = c.pos[3 * (size_t)k + 1]; it.q[2] = c.pos[3 * (size_t)k + 2];
+            it.q[4] = c.radius;
+            it.q[7] = as_float(k);
+            it.q[11] = as_float(ITEM_PARTICLE);
+            boxes[k] = tb;
+            raw[k] = it;
+        }
+        int rc = build_geom(boxes, raw, &cloud_root[ci], &cloud_box[ci]);
+        if (rc) return rc;
+    }
+
     if (fs->camera_medium.is_valid) {
         hs->view_medium = (int)hs->media.size();
         hs->media.push_back(conv_medium(fs->camera_medium));
         hs->has_media = true;
     }
 
-    std::vector<Box> boxes;      /* one per BVH item */
-    std::vector<Item48> raw;     /* same order as boxes */
     Box world;
     world.reset();
 
@@ -369,58 +508,19 @@ int ptr_flatten(const PtrFlatScene *fs, HostScene *hs, std::string *err) {
         if (reverse) pr.flags |= PF_REVERSE;
         if (reverse ^ swaps) pr.flags |= PF_FLIP_N;
 
-        int prim_index = (int)hs->prims.size();
         Box pb;
         pb.reset();
+        pr.root = BVH_NO_CHILD;
         if (pp.shape_type == PTR_SHAPE_MESH) {
-            const HostMesh &hm = hs->meshes[pp.geom];
-            if (boxes.size() + (size_t)hm.n_tris >= (1u << 27)) return fail(err, PTR_ERR_LIMIT, "more than 2^27 BVH items");
-            for (int t = 0; t < hm.n_tris; t++) {
-                const float *v = &hs->tris[9 * (size_t)(hm.tri_base + t)];
-                Box tb;
-                tb.reset();
-                tb.grow(v);
-                tb.grow(v + 3);
-                tb.grow(v + 6);
-                pb.grow(tb);
-                Item48 it;
-                it.q[0] = v[0]; it.q[1] = v[1]; it.q[2] = v[2]; it.q[3] = as_float(prim_index);
-                it.q[4] = v[3]; it.q[5] = v[4]; it.q[6] = v[5]; it.q[7] = as_float(t);
-                it.q[8] = v[6]; it.q[9] = v[7]; it.q[10] = v[8]; it.q[11] = as_float(ITEM_TRI);
-                boxes.push_back(tb);
-                raw.push_back(it);
-            }
-            if (hm.n_tris == 0) continue; /* an empty mesh has no bounds; the reference would crash */
+            if (hs->meshes[pp.geom].n_tris == 0) continue; /* an empty mesh has no bounds; the reference would crash */
+            pb = mesh_box[pp.geom];
+            pr.root = mesh_root[pp.geom];
         } else if (pp.shape_type == PTR_SHAPE_PARTICLECLOUD) {
-            const HostCloud &c = hs->clouds[pp.geom];
-            if (boxes.size() + (size_t)c.n >= (1u << 27)) return fail(err, PTR_ERR_LIMIT, "more than 2^27 BVH items");
-            for (int k = 0; k < c.n; k++) { /* ParticleCloudGetBounds, particlecloud.cpp:284-293 */
-                Box tb;
-                for (int a = 0; a < 3; a++) {
-                    tb.mn[a] = -c.radius + c.pos[3 * (size_t)k + a];
-                    tb.mx[a] = c.radius + c.pos[3 * (size_t)k + a];
-                }
-                pb.grow(tb);
-                Item48 it;
-                memset(&it, 0, sizeof(it));
-                it.q[0] = c.pos[3 * (size_t)k]; it.q[1] = c.pos[3 * (size_t)k + 1]; it.q[2] = c.pos[3 * (size_t)k + 2];
-                it.q[3] = as_float(prim_index);
-                it.q[4] = c.radius;
-                it.q[7] = as_float(k);
-                it.q[11] = as_float(ITEM_PARTICLE);
-                boxes.push_back(tb);
-                raw.push_back(it);
-            }
-            if (c.n == 0) continue;
+            if (hs->clouds[pp.geom].n == 0) continue;
+            pb = cloud_box[pp.geom];
+            pr.root = cloud_root[pp.geom];
         } else {
             pb = xf_bounds16(tw->m, lmin, lmax);
-            Item48 it;
-            memset(&it, 0, sizeof(it));
-            it.q[0] = pb.mn[0]; it.q[1] = pb.mn[1]; it.q[2] = pb.mn[2]; it.q[3] = as_float(prim_index);
-            it.q[4] = pb.mx[0]; it.q[5] = pb.mx[1]; it.q[6] = pb.mx[2];
-            it.q[11] = as_float(ITEM_PRIM);
-            boxes.push_back(pb);
-            raw.push_back(it);
         }
         for (int a = 0; a < 3; a++) { pr.bmin[a] = pb.mn[a]; pr.bmax[a] = pb.mx[a]; }
         world.grow(pb);
@@ -511,27 +611,26 @@ int ptr_flatten(const PtrFlatScene *fs, HostScene *hs, std::string *err) {
     }
     if (hs->lights.size() > PTR_MAX_LIGHTS) return fail(err, PTR_ERR_LIMIT, "more than 256 lights (Aggregator::lightList[256])");
 
-    /* the acceleration structure */
-    if (!boxes.empty()) {
-        Builder b(boxes);
-        Box rb;
-        b.nodes.reserve(boxes.size());
-        b.order.reserve(boxes.size());
-        int32_t root = b.build(0, boxes.size(), &rb, 0);
-        if (root != 0) { /* the whole scene fits one leaf: wrap it */
-            Node64 nd;
-            memset(&nd, 0, sizeof(nd));
-            for (int i = 0; i < 3; i++) { nd.lmin[i] = rb.mn[i]; nd.lmax[i] = rb.mx[i]; }
-            nd.left = root;
-            nd.right = BVH_NO_CHILD;
-            b.nodes.clear();
-            b.nodes.push_back(nd);
+    /* The top level is the reference's own BVH over primitives (primitive.cpp:537-582,620-642):
+     * a few answers depend on the order in which it meets primitives (an SDF hit distance is
+     * measured along the normalised direction and can inflate tMax of a non-unit shadow ray,
+     * procedural.cpp:238; a rectangle's hit can lie in front of its bounds, rectangle.cpp:8 vs
+     * :37-40), and that order follows from the tree.  The tree takes its sort axes from host
+     * rand() (util.h:64-66), drawn exactly as Aggregator::Wrap draws: one call per node of each
+     * mesh BVH, then of each cloud BVH, then of this one.  It holds tens of primitives; the
+     * geometry below it (triangles, particles) lives in the SAH BVHs built above. */
+    {
+        std::vector<char> mesh_done(hs->meshes.size(), 0), cloud_done(hs->clouds.size(), 0);
+        for (const DPrim &pr : hs->prims)
+            if (pr.type == SH_MESH && !mesh_done[pr.geom]) { mesh_done[pr.geom] = 1; burn_bvh_rand(hs->meshes[pr.geom].n_tris, 0, 20); }
+        for (const DPrim &pr : hs->prims)
+            if (pr.type == SH_CLOUD && !cloud_done[pr.geom]) { cloud_done[pr.geom] = 1; burn_bvh_rand(hs->clouds[pr.geom].n, 0, 20); }
+        std::vector<TopHandle> th(hs->prims.size());
+        for (size_t i = 0; i < hs->prims.size(); i++) {
+            for (int a = 0; a < 3; a++) { th[i].pmin[a] = hs->prims[i].bmin[a]; th[i].pmax[a] = hs->prims[i].bmax[a]; }
+            th[i].prim = (int32_t)i;
         }
-        if (b.max_depth + 2 > BVH_STACK) return fail(err, PTR_ERR_LIMIT, "BVH deeper than the traversal stack");
-        hs->bvh_depth = b.max_depth;
-        hs->nodes = std::move(b.nodes);
-        hs->items.resize(b.order.size());
-        for (size_t i = 0; i < b.order.size(); i++) hs->items[i] = raw[b.order[i]];
+        if (!th.empty()) build_top(hs->top, hs->order, th.data(), (int)th.size(), 0, 20, -1);
     }
     return PTR_OK;
 }

@@ -36,6 +36,8 @@ struct HostScene {
     std::vector<HostCloud> clouds;
     std::vector<float> tris;
     std::vector<int32_t> uvidx;
+    std::vector<TopNode> top;   /* the reference's BVH over primitives */
+    std::vector<int32_t> order; /* its leaf handles: primitive indices */
     std::vector<float> env_texels, env_func, env_cdf, env_func_int, env_marg_cdf;
     float env_marg_int = 0;
     int env_w = 0, env_h = 0, env_nu = 0, env_nv = 0;

@@ -446,6 +446,8 @@ int ptr_scene_upload(PtrContext *ctx, const PtrFlatScene *scene) {
     UP(lights, hs.lights)
     UP(tris, hs.tris)
     UP(uvidx, hs.uvidx)
+    UP(order, hs.order)
+    UP(top, hs.top)
     UP(env_texels, hs.env_texels)
     UP(env_func, hs.env_func)
     UP(env_cdf, hs.env_cdf)
@@ -479,6 +481,7 @@ int ptr_scene_upload(PtrContext *ctx, const PtrFlatScene *scene) {
     sc.env_w = hs.env_w; sc.env_h = hs.env_h; sc.env_nu = hs.env_nu; sc.env_nv = hs.env_nv;
     sc.n_prims = (int)hs.prims.size();
     sc.n_lights = (int)hs.lights.size();
+    sc.n_top = (int)hs.top.size();
     sc.n_nodes = (int)hs.nodes.size();
     sc.n_items = (int)hs.items.size();
     sc.view_medium = hs.view_medium;

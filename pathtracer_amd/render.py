@@ -41,8 +41,18 @@ class Renderer:
         capi.check(capi.hip().ptr_set_stream(self._ctx, C.c_void_p(int(hip_stream))))
 
     # -- scene ------------------------------------------------------------------------
-    def upload(self, scene):
-        """scene: BuiltScene / PyScene (anything with a .flat POINTER(PtrFlatScene))."""
+    def upload(self, scene, srand=1):
+        """scene: BuiltScene / PyScene (anything with a .flat POINTER(PtrFlatScene)).
+
+        Like the reference's Aggregator::Wrap, ptr_scene_upload draws from the process's libc
+        rand() (primitive.cpp:541) - it fixes the order in which primitives are visited.  srand
+        (default 1 = a fresh process) reseeds libc first so that an upload is reproducible within
+        a long-lived Python process; pass None to leave the host application's rand() state alone."""
+        if srand is not None:
+            libc = C.CDLL(None)
+            libc.srand(C.c_uint(int(srand)))
+            for _ in range(int(getattr(scene, "rand_calls", 0))):
+                libc.rand()
         capi.check(capi.hip().ptr_scene_upload(self._ctx, scene.flat))
 
     def set_camera(self, cam):

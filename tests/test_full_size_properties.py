@@ -29,7 +29,7 @@ def big(cuda):
 def test_bvh_shape(big):
     sc, r, W, H = big
     info = r.bvh_info()
-    assert info["items"] == 871200 + 1  # every triangle once + the ground sphere
+    assert info["items"] == 871200  # every triangle exactly once (analytic primitives are not BVH items)
     assert info["nodes"] < info["items"]
     assert info["bytes"] == 64 * info["nodes"] + 48 * info["items"]
 
@@ -41,7 +41,7 @@ def test_closest_vs_occluded_consistency(big):
     tmax = np.full(n, FMAX, np.float32)
     g = common.gpu_trace_closest(r, o, d, tmax)
     hit = g["prim"] >= 0
-    assert 0.2 < hit.mean() < 1.0
+    assert 0.2 < hit.mean() <= 1.0  # the ground sphere fills the lower half of the frame
     # any-hit with the same extent agrees with closest-hit on hit / miss
     occ = common.gpu_trace_occluded(r, o, d, tmax)
     assert np.array_equal(occ != 0, hit)

@@ -101,12 +101,6 @@ def test_empty_and_single_ray(scenes):
 
 # image parity: (mean relative error, relative RMSE, fraction of pixels off by > 1e-3 relative)
 IMAGE_CASES = [(s, i) for s in common.SCENES for i in common.INTEGRATORS]
-# Li_VolPath shadows of SDF primitives depend on the reference's BVH visiting order (the SDF hit
-# distance is in normalised-direction units, procedural.cpp:238, and then inflates tMax for the
-# primitives visited after it, light.cpp:10-40): compared on the image mean only.
-ORDER_DEPENDENT = {("zoo", "volpath"), ("zoo_sky_fog", "volpath")}
-
-
 @pytest.mark.parametrize("name,integ", IMAGE_CASES)
 def test_image(scenes, name, integ):
     sc, o, r = scenes(name)
@@ -123,9 +117,6 @@ def test_image(scenes, name, integ):
     assert np.isfinite(img).all()
     assert np.array_equal(smp.reshape(-1), osmp)
     mean_rel, rmse_rel, off = common.image_stats(img, ref)
-    if (name, integ) in ORDER_DEPENDENT:
-        assert mean_rel < 2e-2
-        return
     assert mean_rel < 5e-3, (mean_rel, rmse_rel, off)
     assert rmse_rel < 5e-2, (mean_rel, rmse_rel, off)
     assert off < 0.02, (mean_rel, rmse_rel, off)
