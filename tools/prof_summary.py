@@ -1,0 +1,31 @@
+"""Condense rocprofv3 CSV output (kernel trace / counter collection) into a per-kernel table.
+usage: python tools/prof_summary.py <dir> [<dir> ...] > profiles/<name>.txt"""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = name.split("(")[0]
+    return name.replace("void ", "")
+
+
+for d in sys.argv[1:]:
+    print("== %s" % d)
+    for f in sorted(glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)):
+        print("-- kernel stats (%s)" % os.path.basename(f))
+        for row in csv.DictReader(open(f)):
+            print("  %-34s calls %6s  total_ns %14s  avg_ns %12s  pct %6s" % (short(row.get("Name", "")), row.get("Calls"), row.get("TotalDurationNs"),
+                                                                               row.get("AverageNs"), row.get("Percentage")))
+    for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
+        print("-- counters (%s)" % os.path.basename(f))
+        acc = defaultdict(lambda: defaultdict(float))
+        calls = defaultdict(set)
+        for row in csv.DictReader(open(f)):
+            k = short(row.get("Kernel_Name", ""))
+            acc[k][row.get("Counter_Name")] += float(row.get("Counter_Value") or 0)
+            calls[k].add(row.get("Dispatch_Id"))
+        for k in sorted(acc):
+            print("  %-34s dispatches %5d  " % (k, len(calls[k])) + "  ".join("%s=%.6g" % (c, v) for c, v in sorted(acc[k].items())))
