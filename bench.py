@@ -27,13 +27,6 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
-class _DevArray:
-    """Wraps a raw device pointer for torch.as_tensor (CUDA array interface v2)."""
-
-    def __init__(self, ptr, shape, typestr):
-        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
-
-
 def ray_count(c):
     return c["total_paths"] + c["shadow_rays"] + c["mis_rays"] + c["probe_rays"]
 
@@ -82,12 +75,11 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+    from pathtracer_amd import dist as pdist
+
     dist = None
     if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        dist = pdist.init_process_group("nccl")
     else:
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -129,9 +121,7 @@ def main():
     r.film_init(W, H, args.seed)  # the timed region starts from a clean film
     r.shard(rank, world)
 
-    we_p, acc_p, smp_p = r.film_device_ptrs()
-    we_t = torch.as_tensor(_DevArray(we_p, (H * W * 3,), "<f4"), device=dev)
-    acc_t = torch.as_tensor(_DevArray(acc_p, (H * W,), "<f8"), device=dev)
+    we_t, acc_t, smp_t = pdist.film_tensors(r, dev)
 
     barrier()
     t0 = time.perf_counter()
@@ -139,8 +129,7 @@ def main():
         step()
     r.sync()
     if dist is not None:
-        dist.all_reduce(we_t)
-        dist.all_reduce(acc_t)
+        pdist.all_reduce_film(dist, we_t, acc_t, smp_t)
     barrier()
     dt = time.perf_counter() - t0
 

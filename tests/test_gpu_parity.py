@@ -200,3 +200,23 @@ def test_errors(cuda):
         with pytest.raises(pa.PtrError) as e:
             r.upload(sc)
         assert e.value.code == pa.capi.PTR_ERR_LIMIT
+
+
+def test_film_tensor_views_for_the_all_reduce(scenes):
+    """pathtracer_amd.dist.film_tensors: torch views of the accumulators inside the library (what
+    the RCCL all-reduce of bench.py operates on) alias the film the C-ABI reads back"""
+    import torch
+    from pathtracer_amd import dist as pdist
+
+    sc, o, r = scenes("cornell")
+    r.film_init(W, H, SEED)
+    r.render(2, pa.LI_PATH)
+    r.sync()
+    we_t, acc_t, smp_t = pdist.film_tensors(r, torch.device("cuda:0"))
+    we, acc, smp = r.film()
+    assert np.array_equal(we_t.cpu().numpy(), we.reshape(-1))
+    assert np.array_equal(acc_t.cpu().numpy(), acc.reshape(-1))
+    assert np.array_equal(smp_t.cpu().numpy(), smp.reshape(-1))
+    we_t.mul_(2.0)  # in place on the device: visible through ptr_film_read
+    torch.cuda.synchronize()
+    assert np.array_equal(r.film()[0], we * 2)
