@@ -53,18 +53,30 @@ PD bool slab_test(const float *bmin, const float *bmax, const f3 &o, const f3 &i
     return true;
 }
 
-/* ---- triangle, mesh.cpp:162-249 (watertight test, double fallback for zero edge functions) ---- */
-PD bool tri_hit(const f3 &ro, const f3 &rd, float tmax, const f3 &p0, const f3 &p1, const f3 &p2, float *tHit, float *ob0,
-                float *ob1, float *ob2) {
+/* ---- triangle, mesh.cpp:162-249 (watertight test, double fallback for zero edge functions) ----
+ * The permutation and shear depend on the ray only (mesh.cpp:176-186); the reference recomputes
+ * them for every triangle, here they are set up once per ray - same operations, same values. */
+struct TriRay {
+    int kx, ky, kz;
+    float Sx, Sy, Sz;
+};
+PD TriRay tri_ray_setup(const f3 &rd) {
+    TriRay tr;
+    tr.kz = max_dim(abs3(rd));
+    tr.kx = tr.kz + 1; if (tr.kx == 3) tr.kx = 0;
+    tr.ky = tr.kx + 1; if (tr.ky == 3) tr.ky = 0;
+    f3 d(comp(rd, tr.kx), comp(rd, tr.ky), comp(rd, tr.kz));
+    tr.Sx = -d.x / d.z; tr.Sy = -d.y / d.z; tr.Sz = 1.f / d.z;
+    return tr;
+}
+
+PD bool tri_hit_pre(const f3 &ro, const TriRay &tr, float tmax, const f3 &p0, const f3 &p1, const f3 &p2, float *tHit, float *ob0,
+                    float *ob1, float *ob2) {
     f3 p0t = p0 - ro, p1t = p1 - ro, p2t = p2 - ro;
-    int kz = max_dim(abs3(rd));
-    int kx = kz + 1; if (kx == 3) kx = 0;
-    int ky = kx + 1; if (ky == 3) ky = 0;
-    f3 d(comp(rd, kx), comp(rd, ky), comp(rd, kz));
-    p0t = f3(comp(p0t, kx), comp(p0t, ky), comp(p0t, kz));
-    p1t = f3(comp(p1t, kx), comp(p1t, ky), comp(p1t, kz));
-    p2t = f3(comp(p2t, kx), comp(p2t, ky), comp(p2t, kz));
-    float Sx = -d.x / d.z, Sy = -d.y / d.z, Sz = 1.f / d.z;
+    p0t = f3(comp(p0t, tr.kx), comp(p0t, tr.ky), comp(p0t, tr.kz));
+    p1t = f3(comp(p1t, tr.kx), comp(p1t, tr.ky), comp(p1t, tr.kz));
+    p2t = f3(comp(p2t, tr.kx), comp(p2t, tr.ky), comp(p2t, tr.kz));
+    const float Sx = tr.Sx, Sy = tr.Sy, Sz = tr.Sz;
     p0t.x += Sx * p0t.z; p0t.y += Sy * p0t.z;
     p1t.x += Sx * p1t.z; p1t.y += Sy * p1t.z;
     p2t.x += Sx * p2t.z; p2t.y += Sy * p2t.z;
@@ -102,6 +114,11 @@ PD bool tri_hit(const f3 &ro, const f3 &rd, float tmax, const f3 &p0, const f3 &
     *tHit = t;
     *ob0 = b0; *ob1 = b1; *ob2 = b2;
     return true;
+}
+PD bool tri_hit(const f3 &ro, const f3 &rd, float tmax, const f3 &p0, const f3 &p1, const f3 &p2, float *tHit, float *ob0,
+                float *ob1, float *ob2) {
+    TriRay tr = tri_ray_setup(rd);
+    return tri_hit_pre(ro, tr, tmax, p0, p1, p2, tHit, ob0, ob1, ob2);
 }
 
 /* ---- sphere, sphere.cpp:105-127.  Object-space ray given.  Every sphere the scene API can make
@@ -260,33 +277,56 @@ PD bool shape_hit_t(const DPrim &pr, const f3 &ro, const f3 &rd, float tmax, flo
  * exclude them.  ANY = true returns at the first accepted hit. */
 struct TraceStats { unsigned nodes, items; };
 
+/* Per-lane traversal stack: the first LDS_STACK entries live in LDS (column threadIdx.x of a
+ * [LDS_STACK][block] array: conflict-free, and a pop no longer waits on a scratch load), deeper
+ * entries spill to a small scratch array that well-built trees rarely reach. */
+#define LDS_STACK 24
+#define OVF_STACK (BVH_STACK - LDS_STACK)
+#define TRACE_TPB 256
+struct LaneStack {
+    int *lds; /* &smem[threadIdx.x], stride TRACE_TPB */
+};
+#define STACK_PUSH(v)                                   \
+    do {                                                \
+        if (sp < LDS_STACK) ls.lds[sp * TRACE_TPB] = (v); \
+        else if (sp < BVH_STACK) ovf[sp - LDS_STACK] = (v); \
+        sp++;                                           \
+    } while (0)
+#define STACK_POP() (--sp, sp < LDS_STACK ? ls.lds[sp * TRACE_TPB] : ovf[(sp < BVH_STACK ? sp : BVH_STACK - 1) - LDS_STACK])
+
 template <bool ANY, bool COUNT>
 PD bool bvh_closest(const DScene &sc, int root, const f3 &ro, const f3 &rd, const f3 &inv, float &tmax, int &hface, float &hb0,
-                    float &hb1, TraceStats *st) {
-    int stack[BVH_STACK];
+                    float &hb1, TraceStats *st, const LaneStack &ls) {
+    int ovf[OVF_STACK];
     int sp = 0;
     bool hit = false;
     int node = root;
+    const TriRay tr = tri_ray_setup(rd);
+    const int DONE = 0x7FFFFFFF;
     while (true) {
-        if (node >= 0) {
+        /* descend until this lane holds a leaf (or has nothing left) */
+        while (node >= 0 && node != DONE) {
             const float4 *np = reinterpret_cast<const float4 *>(sc.nodes + node);
             float4 a = np[0], b = np[1], c = np[2], d = np[3];
             float lmin[3] = {a.x, a.y, a.z}, lmax[3] = {a.w, b.x, b.y};
             float rmin[3] = {b.z, b.w, c.x}, rmax[3] = {c.y, c.z, c.w};
             int left = __float_as_int(d.x), right = __float_as_int(d.y);
-            float tl, tr;
+            float tl, tr0;
             bool hl = slab_test(lmin, lmax, ro, inv, tmax, &tl);
-            bool hr = slab_test(rmin, rmax, ro, inv, tmax, &tr);
+            bool hr = slab_test(rmin, rmax, ro, inv, tmax, &tr0);
             if (COUNT) st->nodes += 2;
             if (hl && hr) {
                 int first = left, second = right;
-                if (tr < tl) { first = right; second = left; }
-                if (sp < BVH_STACK) stack[sp++] = second;
+                if (tr0 < tl) { first = right; second = left; }
+                STACK_PUSH(second);
                 node = first;
-                continue;
-            } else if (hl) { node = left; continue; }
-            else if (hr) { node = right; continue; }
-        } else {
+            } else if (hl) node = left;
+            else if (hr) node = right;
+            else if (sp == 0) node = DONE;
+            else node = STACK_POP();
+        }
+        if (node == DONE) break;
+        {
             unsigned packed = (unsigned)(-(node + 1));
             unsigned first = packed & 0x07FFFFFFu, n = (packed >> 27) + 1;
             for (unsigned i = 0; i < n; i++) {
@@ -296,7 +336,7 @@ PD bool bvh_closest(const DScene &sc, int root, const f3 &ro, const f3 &rd, cons
                 if (COUNT) st->items += 1;
                 if (kind == ITEM_TRI) {
                     float t, b0, b1, b2;
-                    if (tri_hit(ro, rd, tmax, f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), &t, &b0, &b1, &b2)) {
+                    if (tri_hit_pre(ro, tr, tmax, f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), &t, &b0, &b1, &b2)) {
                         tmax = t; hface = __float_as_int(q1.w); hb0 = b0; hb1 = b1; hit = true;
                         if (ANY) return true;
                     }
@@ -312,7 +352,7 @@ PD bool bvh_closest(const DScene &sc, int root, const f3 &ro, const f3 &rd, cons
             }
         }
         if (sp == 0) break;
-        node = stack[--sp];
+        node = STACK_POP();
     }
     return hit;
 }
@@ -320,12 +360,12 @@ PD bool bvh_closest(const DScene &sc, int root, const f3 &ro, const f3 &rd, cons
 /* PrimitiveIntersect (primitive.cpp:52-73) for the primitive of a top-level leaf */
 template <bool ANY, bool COUNT>
 PD bool prim_closest(const DScene &sc, int p, const f3 &ro, const f3 &rd, const f3 &inv, float &tmax, int &hprim, int &hface,
-                     float &hb0, float &hb1, TraceStats *st) {
+                     float &hb0, float &hb1, TraceStats *st, const LaneStack &ls) {
     const DPrim &pr = sc.prims[p];
     if (pr.type == SH_MESH || pr.type == SH_CLOUD) {
         /* Mesh::Intersect / ParticleCloud::Intersect start with their own root box, which is
          * the primitive's bound the leaf just passed: go straight to the geometry BVH */
-        if (bvh_closest<ANY, COUNT>(sc, pr.root, ro, rd, inv, tmax, hface, hb0, hb1, st)) { hprim = p; return true; }
+        if (bvh_closest<ANY, COUNT>(sc, pr.root, ro, rd, inv, tmax, hface, hb0, hb1, st, ls)) { hprim = p; return true; }
         return false;
     }
     float t;
@@ -341,7 +381,7 @@ PD bool prim_closest(const DScene &sc, int p, const f3 &ro, const f3 &rd, const 
 /* Aggregator::Intersect, primitive.cpp:374-431, step for step over the reference's own tree */
 template <bool ANY, bool COUNT>
 PD bool traverse(const DScene &sc, const f3 &ro, const f3 &rd, float &tmax, int &hprim, int &hface, float &hb0, float &hb1,
-                 TraceStats *st) {
+                 TraceStats *st, const LaneStack &ls) {
     if (sc.n_top == 0) return false;
     f3 inv(1 / rd.x, 1 / rd.y, 1 / rd.z);
     bool hit = false;
@@ -356,7 +396,7 @@ PD bool traverse(const DScene &sc, const f3 &ro, const f3 &rd, float &tmax, int 
         if (slab_test(nd.bmin, nd.bmax, ro, inv, tmax, &te)) {
             if (nd.left < 0) {
                 for (int i = 0; i < nd.n; i++) {
-                    if (prim_closest<ANY, COUNT>(sc, sc.order[nd.first + i], ro, rd, inv, tmax, hprim, hface, hb0, hb1, st)) {
+                    if (prim_closest<ANY, COUNT>(sc, sc.order[nd.first + i], ro, rd, inv, tmax, hprim, hface, hb0, hb1, st, ls)) {
                         hit = true;
                         if (ANY) return true;
                     }

@@ -37,8 +37,13 @@ struct f2 {
 PD float fmaxr(float a, float b) { return a < b ? b : a; } /* geometry.h:84 Max */
 PD float fminr(float a, float b) { return a < b ? a : b; } /* geometry.h:85 Min */
 PD float absr(float v) { return v > 0 ? v : -v; }          /* geometry.h:86 Absf */
-PD bool is_zero(float a) { return (double)absr(a) < 1e-9; }
-PD bool is_unsafe_hit(float a) { return (double)absr(a) < 1e-6; }
+/* IsZero / IsUnsafeHit compare Absf(a) with a double literal (1e-9, 1e-6).  The floats below such
+ * a literal are exactly the floats below the first float >= it, so the conversion can be skipped. */
+PD bool is_zero(float a) { return absr(a) < 1.00000008e-09f; }
+PD bool is_unsafe_hit(float a) { return absr(a) < 1.00000011e-06f; }
+static_assert((double)1.00000008e-09f >= 1e-9 && (double)9.99999972e-10f < 1e-9, "IsZero threshold");
+static_assert((double)1.00000011e-06f >= 1e-6 && (double)9.99999997e-07f < 1e-6, "IsUnsafeHit threshold");
+static_assert(9.99999972e-10f < 1.00000008e-09f && 9.99999997e-07f < 1.00000011e-06f, "adjacent floats");
 PD float clampr(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
 PD int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 PD float gammar(int n) { return ((float)n * kMachineEpsilon) / (1 - (float)n * kMachineEpsilon); }

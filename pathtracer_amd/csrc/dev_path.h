@@ -335,7 +335,7 @@ PD VertexOut shade_vertex(const DScene &sc, int integrator, Rng &rng, f3 &ro, f3
 struct NeeCtr { unsigned shadow, mis, zero; };
 
 /* VisibilityTester::Tr, light.cpp:10-40 */
-PD f3 vis_tr(const DScene &sc, const NeeRec &rec, NeeCtr &ctr) {
+PD f3 vis_tr(const DScene &sc, const NeeRec &rec, NeeCtr &ctr, const LaneStack &ls) {
     f3 ro = ld3(rec.oA), rd = ld3(rec.dA);
     int med = rec.medA;
     LightPoint p1;
@@ -346,7 +346,7 @@ PD f3 vis_tr(const DScene &sc, const NeeRec &rec, NeeCtr &ctr) {
         int hp = -1, hf = 0;
         float b0, b1;
         ctr.shadow++;
-        bool hit = traverse<false, false>(sc, ro, rd, tmax, hp, hf, b0, b1, nullptr);
+        bool hit = traverse<false, false>(sc, ro, rd, tmax, hp, hf, b0, b1, nullptr, ls);
         if (hit && sc.prims[hp].material >= 0) return f3(0.0f);
         if (med >= 0) Tr *= medium_tr(sc.media[med], rd, tmax);
         if (!hit || (sc.prims[hp].flags & PF_EMISSIVE)) break;
@@ -357,14 +357,14 @@ PD f3 vis_tr(const DScene &sc, const NeeRec &rec, NeeCtr &ctr) {
     return Tr;
 }
 /* Aggregator::IntersectTr, primitive.cpp:433-461 */
-PD bool intersect_tr(const DScene &sc, f3 ro, const f3 &rd, int med, int *hprim, f3 *Tr, NeeCtr &ctr) {
+PD bool intersect_tr(const DScene &sc, f3 ro, const f3 &rd, int med, int *hprim, f3 *Tr, NeeCtr &ctr, const LaneStack &ls) {
     *Tr = f3(1.f);
     for (int guard = 0; guard < 256; guard++) {
         float tmax = kInfinity;
         int hp = -1, hf = 0;
         float b0, b1;
         ctr.mis++;
-        bool hit = traverse<false, false>(sc, ro, rd, tmax, hp, hf, b0, b1, nullptr);
+        bool hit = traverse<false, false>(sc, ro, rd, tmax, hp, hf, b0, b1, nullptr, ls);
         if (med >= 0) *Tr *= medium_tr(sc.media[med], rd, tmax);
         if (!hit || (sc.prims[hp].flags & PF_EMISSIVE)) return false;
         if (sc.prims[hp].material >= 0) { *hprim = hp; return true; }
@@ -376,19 +376,39 @@ PD bool intersect_tr(const DScene &sc, f3 ro, const f3 &rd, int med, int *hprim,
     return false;
 }
 
-PD f3 resolve_nee(const DScene &sc, const NeeRec &rec, NeeCtr &ctr) {
+/* Stage 1 of a direct-light record: the visibility / transmittance query of the light-sampling
+ * half (primitive.cpp:283-290).  Leaves Li·Tr (or 0) in rec->LiA.
+ * LOOP = false is valid whenever the walk of VisibilityTester::Tr cannot go past its first hit:
+ * outside Li_VolPath (Unoccluded, light.cpp:5-8), or when every primitive has a material - then
+ * "any hit" decides, and the medium term is that of the unbroken segment. */
+template <bool LOOP>
+PD void nee_shadow(const DScene &sc, NeeRec *rec, NeeCtr &ctr, const LaneStack &ls) {
+    f3 Li = ld3(rec->LiA);
+    const bool medium = (rec->flags & NEE_MEDIUM) != 0;
+    if (LOOP) Li *= vis_tr(sc, *rec, ctr, ls);
+    else {
+        float tmax = 1 - kShadowEpsilon;
+        int hp = -1, hf = 0;
+        float b0, b1;
+        ctr.shadow++;
+        f3 rd = ld3(rec->dA);
+        if (traverse<true, false>(sc, ld3(rec->oA), rd, tmax, hp, hf, b0, b1, nullptr, ls)) Li = f3(0.f);
+        else if (medium) {
+            f3 Tr(1.f);
+            if (rec->medA >= 0) Tr *= medium_tr(sc.media[rec->medA], rd, tmax);
+            Li *= Tr;
+        }
+    }
+    st3(rec->LiA, Li);
+}
+
+/* Stage 2: the query of the BSDF / phase-sampling half (primitive.cpp:315-336) and the sum */
+template <bool LOOP>
+PD f3 nee_mis_resolve(const DScene &sc, const NeeRec &rec, NeeCtr &ctr, const LaneStack &ls) {
     f3 Ld(0.f);
     const bool medium = (rec.flags & NEE_MEDIUM) != 0;
     if (rec.flags & NEE_A) {
         f3 Li = ld3(rec.LiA);
-        if (medium) Li *= vis_tr(sc, rec, ctr);
-        else {
-            float tmax = 1 - kShadowEpsilon;
-            int hp = -1, hf = 0;
-            float b0, b1;
-            ctr.shadow++;
-            if (traverse<true, false>(sc, ld3(rec.oA), ld3(rec.dA), tmax, hp, hf, b0, b1, nullptr)) Li = f3(0.f);
-        }
         if (!is_black(Li)) Ld += ld3(rec.fA) * Li * rec.wA / rec.pdfA;
     }
     if (rec.flags & NEE_B) {
@@ -396,13 +416,17 @@ PD f3 resolve_nee(const DScene &sc, const NeeRec &rec, NeeCtr &ctr) {
         bool found;
         int hp = -1;
         f3 rd = ld3(rec.dB);
-        if (medium) found = intersect_tr(sc, ld3(rec.oB), rd, rec.medB, &hp, &Tr, ctr);
+        if (LOOP) found = intersect_tr(sc, ld3(rec.oB), rd, rec.medB, &hp, &Tr, ctr, ls);
         else {
             float tmax = kInfinity;
             int hf = 0;
             float b0, b1;
             ctr.mis++;
-            found = traverse<false, false>(sc, ld3(rec.oB), rd, tmax, hp, hf, b0, b1, nullptr);
+            found = traverse<false, false>(sc, ld3(rec.oB), rd, tmax, hp, hf, b0, b1, nullptr, ls);
+            if (medium) {
+                if (rec.medB >= 0) Tr *= medium_tr(sc.media[rec.medB], rd, tmax);
+                if (found && (sc.prims[hp].flags & PF_EMISSIVE)) found = false; /* IntersectTr: an emitter ends the walk with "false" */
+            }
         }
         f3 Li2(0.f);
         if (found) {

@@ -132,6 +132,9 @@ template <bool COUNT>
 __global__ void __launch_bounds__(TPB) k_trace_closest(DScene sc, int n, const int *queue, int stride, const float *o, const float *d,
                                                        const float *tmax_in, int *hprim, int *hface, float *ht, float *hb0, float *hb1,
                                                        unsigned long long *ctrs) {
+    __shared__ int s_stack[LDS_STACK * TRACE_TPB];
+    LaneStack ls;
+    ls.lds = &s_stack[threadIdx.x];
     int i = blockIdx.x * TPB + threadIdx.x;
     TraceStats st;
     st.nodes = 0;
@@ -143,12 +146,17 @@ __global__ void __launch_bounds__(TPB) k_trace_closest(DScene sc, int n, const i
         float tmax = tmax_in ? tmax_in[slot] : kInfinity;
         int hp = -1, hf = -1;
         float b0 = 0, b1 = 0;
-        bool hit = traverse<false, COUNT>(sc, ro, rd, tmax, hp, hf, b0, b1, &st);
+        bool hit = traverse<false, COUNT>(sc, ro, rd, tmax, hp, hf, b0, b1, &st, ls);
         hprim[slot] = hit ? hp : -1;
         hface[slot] = hit ? hf : -1;
         ht[slot] = tmax;
-        if (hb0) hb0[slot] = hit ? b0 : 0;
-        if (hb1) hb1[slot] = hit ? b1 : 0;
+        if (COUNT && hb0 && hb1) { /* profiling: per-ray work instead of barycentrics (ptr_profile_enable bit 1) */
+            hb0[slot] = (float)st.nodes;
+            hb1[slot] = (float)st.items;
+        } else {
+            if (hb0) hb0[slot] = hit ? b0 : 0;
+            if (hb1) hb1[slot] = hit ? b1 : 0;
+        }
     }
     if (COUNT) {
         ctr_flush(ctrs, C_NODES, st.nodes);
@@ -157,6 +165,9 @@ __global__ void __launch_bounds__(TPB) k_trace_closest(DScene sc, int n, const i
 }
 
 __global__ void __launch_bounds__(TPB) k_trace_occluded(DScene sc, int n, const float *o, const float *d, const float *tmax_in, int *occ) {
+    __shared__ int s_stack[LDS_STACK * TRACE_TPB];
+    LaneStack ls;
+    ls.lds = &s_stack[threadIdx.x];
     int i = blockIdx.x * TPB + threadIdx.x;
     if (i >= n) return;
     f3 ro(o[i], o[n + i], o[2 * n + i]);
@@ -164,15 +175,15 @@ __global__ void __launch_bounds__(TPB) k_trace_occluded(DScene sc, int n, const 
     float tmax = tmax_in ? tmax_in[i] : kInfinity;
     int hp = -1, hf = -1;
     float b0, b1;
-    occ[i] = traverse<true, false>(sc, ro, rd, tmax, hp, hf, b0, b1, nullptr) ? 1 : 0;
+    occ[i] = traverse<true, false>(sc, ro, rd, tmax, hp, hf, b0, b1, nullptr, ls) ? 1 : 0;
 }
 
 __global__ void __launch_bounds__(TPB) k_shade(DScene sc, Pipe pp, PassParams prm, int n, const int *queue, int *q_next, int *q_nee,
-                                               int *counts, unsigned long long *ctrs) {
+                                               int *q_shadow, int *counts, unsigned long long *ctrs) {
     int i = blockIdx.x * TPB + threadIdx.x;
     VertexCtr ctr;
     ctr.total = ctr.miss = ctr.surf = ctr.med = ctr.light = ctr.zero = 0;
-    bool alive = false, want_nee = false;
+    bool alive = false, want_nee = false, want_shadow = false;
     int slot = 0;
     if (i < n) {
         slot = queue ? queue[i] : i;
@@ -190,6 +201,7 @@ __global__ void __launch_bounds__(TPB) k_shade(DScene sc, Pipe pp, PassParams pr
                                     pflags, &pp.nee[slot], ctr);
         alive = vo.alive;
         want_nee = vo.want_nee;
+        want_shadow = want_nee && (pp.nee[slot].flags & NEE_A);
         st3(ps.L, L);
         st3(ps.beta, beta);
         ps.medium = med;
@@ -204,6 +216,7 @@ __global__ void __launch_bounds__(TPB) k_shade(DScene sc, Pipe pp, PassParams pr
     }
     queue_append(&counts[0], q_next, alive, slot);
     queue_append(&counts[1], q_nee, want_nee, slot);
+    queue_append(&counts[2], q_shadow, want_shadow, slot);
     ctr_flush(ctrs, C_TOTAL, ctr.total);
     ctr_flush(ctrs, C_MISS, ctr.miss);
     ctr_flush(ctrs, C_SURF, ctr.surf);
@@ -212,19 +225,34 @@ __global__ void __launch_bounds__(TPB) k_shade(DScene sc, Pipe pp, PassParams pr
     ctr_flush(ctrs, C_ZERO, ctr.zero);
 }
 
-__global__ void __launch_bounds__(TPB) k_nee(DScene sc, Pipe pp, int n, const int *queue, unsigned long long *ctrs) {
+template <bool LOOP>
+__global__ void __launch_bounds__(TPB) k_shadow(DScene sc, Pipe pp, int n, const int *queue, unsigned long long *ctrs) {
+    __shared__ int s_stack[LDS_STACK * TRACE_TPB];
+    LaneStack ls;
+    ls.lds = &s_stack[threadIdx.x];
+    int i = blockIdx.x * TPB + threadIdx.x;
+    NeeCtr ctr;
+    ctr.shadow = ctr.mis = ctr.zero = 0;
+    if (i < n) nee_shadow<LOOP>(sc, &pp.nee[queue[i]], ctr, ls);
+    ctr_flush(ctrs, C_SHADOW, ctr.shadow);
+}
+
+template <bool LOOP>
+__global__ void __launch_bounds__(TPB) k_mis(DScene sc, Pipe pp, int n, const int *queue, unsigned long long *ctrs) {
+    __shared__ int s_stack[LDS_STACK * TRACE_TPB];
+    LaneStack ls;
+    ls.lds = &s_stack[threadIdx.x];
     int i = blockIdx.x * TPB + threadIdx.x;
     NeeCtr ctr;
     ctr.shadow = ctr.mis = ctr.zero = 0;
     if (i < n) {
         int slot = queue[i];
-        f3 Ld = resolve_nee(sc, pp.nee[slot], ctr);
+        f3 Ld = nee_mis_resolve<LOOP>(sc, pp.nee[slot], ctr, ls);
         PathRec *ps = &pp.paths[slot];
         f3 L = ld3(ps->L);
         L += Ld;
         st3(ps->L, L);
     }
-    ctr_flush(ctrs, C_SHADOW, ctr.shadow);
     ctr_flush(ctrs, C_MIS, ctr.mis);
     ctr_flush(ctrs, C_ZERO, ctr.zero);
 }
@@ -259,9 +287,9 @@ static int set_err(int code, const std::string &msg) {
         if (e_ != hipSuccess) return set_err(PTR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-enum { K_RAYGEN = 0, K_TRACE, K_SHADE, K_NEE, K_FILM, K_API_CLOSEST, K_API_OCCLUDED, K_API_RAYGEN };
-static const char *kKernelNames[PTR_PROF_KERNELS] = {"raygen", "trace_closest", "shade", "nee", "film", "api_trace_closest",
-                                                     "api_trace_occluded", "api_generate_rays"};
+enum { K_RAYGEN = 0, K_TRACE, K_SHADE, K_SHADOW, K_MIS, K_FILM, K_API_CLOSEST, K_API_OCCLUDED };
+static const char *kKernelNames[PTR_PROF_KERNELS] = {"raygen", "trace_closest", "shade", "nee_shadow", "nee_mis", "film", "api_trace_closest",
+                                                     "api_trace_occluded"};
 
 struct ProfSpan {
     hipEvent_t a, b;
@@ -275,7 +303,7 @@ struct PtrContext {
     std::vector<void *> scene_allocs;
     DScene sc;
     bool has_scene = false, has_camera = false, has_film = false;
-    bool scene_has_media = false;
+    bool scene_has_media = false, scene_all_opaque = false;
     DCamera cam;
     int64_t bvh_bytes = 0;
     /* film */
@@ -287,8 +315,8 @@ struct PtrContext {
     int sample_cursor = 0, shard_offset = 0, shard_stride = 1;
     /* pipeline */
     Pipe pipe;
-    int *queues[3] = {nullptr, nullptr, nullptr};
-    int *counts = nullptr;      /* device: [0] next, [1] nee */
+    int *queues[4] = {nullptr, nullptr, nullptr, nullptr};
+    int *counts = nullptr;      /* device: [0] next, [1] nee, [2] shadow */
     int *counts_host = nullptr; /* pinned */
     int nb_max = 1;
     unsigned long long *ctrs = nullptr;
@@ -324,13 +352,13 @@ static void free_scene(PtrContext *ctx) {
 }
 static void free_film(PtrContext *ctx) {
     void *ptrs[] = {ctx->we, ctx->acc, ctx->samples, ctx->pipe.ro, ctx->pipe.rd, ctx->pipe.hprim, ctx->pipe.hface, ctx->pipe.ht,
-                    ctx->pipe.paths, ctx->pipe.nee, ctx->queues[0], ctx->queues[1], ctx->queues[2], ctx->counts};
+                    ctx->pipe.paths, ctx->pipe.nee, ctx->queues[0], ctx->queues[1], ctx->queues[2], ctx->queues[3], ctx->counts};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (ctx->counts_host) (void)hipHostFree(ctx->counts_host);
     ctx->we = nullptr; ctx->acc = nullptr; ctx->samples = nullptr;
     memset(&ctx->pipe, 0, sizeof(ctx->pipe));
-    ctx->queues[0] = ctx->queues[1] = ctx->queues[2] = nullptr;
+    ctx->queues[0] = ctx->queues[1] = ctx->queues[2] = ctx->queues[3] = nullptr;
     ctx->counts = nullptr;
     ctx->counts_host = nullptr;
     ctx->has_film = false;
@@ -489,6 +517,9 @@ int ptr_scene_upload(PtrContext *ctx, const PtrFlatScene *scene) {
     ctx->sc = sc;
     ctx->bvh_bytes = (int64_t)(hs.nodes.size() * sizeof(Node64) + hs.items.size() * sizeof(Item48));
     ctx->scene_has_media = hs.has_media;
+    ctx->scene_all_opaque = true;
+    for (const DPrim &pr : hs.prims)
+        if (pr.material < 0) ctx->scene_all_opaque = false;
     ctx->has_scene = true;
     return PTR_OK;
 }
@@ -533,9 +564,9 @@ int ptr_film_init(PtrContext *ctx, int width, int height, uint64_t seed) {
         HIPCHK(hipMalloc((void **)&ctx->pipe.ht, sizeof(float) * cap));
         HIPCHK(hipMalloc((void **)&ctx->pipe.paths, sizeof(PathRec) * cap));
         HIPCHK(hipMalloc((void **)&ctx->pipe.nee, sizeof(NeeRec) * cap));
-        for (int q = 0; q < 3; q++) HIPCHK(hipMalloc((void **)&ctx->queues[q], sizeof(int) * cap));
-        HIPCHK(hipMalloc((void **)&ctx->counts, 2 * sizeof(int)));
-        HIPCHK(hipHostMalloc((void **)&ctx->counts_host, 2 * sizeof(int), hipHostMallocDefault));
+        for (int q = 0; q < 4; q++) HIPCHK(hipMalloc((void **)&ctx->queues[q], sizeof(int) * cap));
+        HIPCHK(hipMalloc((void **)&ctx->counts, 4 * sizeof(int)));
+        HIPCHK(hipHostMalloc((void **)&ctx->counts_host, 4 * sizeof(int), hipHostMallocDefault));
         ctx->pipe.cap = (int)cap;
     }
     ctx->width = width;
@@ -580,8 +611,8 @@ static int run_pass(PtrContext *ctx, int first, int step, int nb, int integrator
     int qi = 0;
     for (int iter = 0; n_cur > 0 && iter < 4096; iter++) {
         int *q_next = ctx->queues[qi];
-        int *q_nee = ctx->queues[2];
-        HIPCHK(hipMemsetAsync(ctx->counts, 0, 2 * sizeof(int), s));
+        int *q_nee = ctx->queues[2], *q_shadow = ctx->queues[3];
+        HIPCHK(hipMemsetAsync(ctx->counts, 0, 4 * sizeof(int), s));
         {
             ProfScope ps(ctx, K_TRACE, (uint64_t)n_cur);
             if (ctx->count_traversal)
@@ -595,15 +626,24 @@ static int run_pass(PtrContext *ctx, int first, int step, int nb, int integrator
         }
         {
             ProfScope ps(ctx, K_SHADE, (uint64_t)n_cur);
-            hipLaunchKernelGGL(k_shade, dim3(nblocks(n_cur)), dim3(TPB), 0, s, ctx->sc, ctx->pipe, prm, n_cur, q_cur, q_next, q_nee,
+            hipLaunchKernelGGL(k_shade, dim3(nblocks(n_cur)), dim3(TPB), 0, s, ctx->sc, ctx->pipe, prm, n_cur, q_cur, q_next, q_nee, q_shadow,
                                ctx->counts, ctx->ctrs);
         }
-        HIPCHK(hipMemcpyAsync(ctx->counts_host, ctx->counts, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(ctx->counts_host, ctx->counts, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
-        int n_next = ctx->counts_host[0], n_nee = ctx->counts_host[1];
+        int n_next = ctx->counts_host[0], n_nee = ctx->counts_host[1], n_shadow = ctx->counts_host[2];
+        /* the walks of VisibilityTester::Tr / IntersectTr can only go past their first hit under
+         * Li_VolPath and only if some primitive has no material (medium boundary, emitter) */
+        const bool loop = integrator == PTR_LI_VOLPATH && !ctx->scene_all_opaque;
+        if (n_shadow > 0) {
+            ProfScope ps(ctx, K_SHADOW, (uint64_t)n_shadow);
+            if (loop) hipLaunchKernelGGL(k_shadow<true>, dim3(nblocks(n_shadow)), dim3(TPB), 0, s, ctx->sc, ctx->pipe, n_shadow, (const int *)q_shadow, ctx->ctrs);
+            else hipLaunchKernelGGL(k_shadow<false>, dim3(nblocks(n_shadow)), dim3(TPB), 0, s, ctx->sc, ctx->pipe, n_shadow, (const int *)q_shadow, ctx->ctrs);
+        }
         if (n_nee > 0) {
-            ProfScope ps(ctx, K_NEE, (uint64_t)n_nee);
-            hipLaunchKernelGGL(k_nee, dim3(nblocks(n_nee)), dim3(TPB), 0, s, ctx->sc, ctx->pipe, n_nee, (const int *)q_nee, ctx->ctrs);
+            ProfScope ps(ctx, K_MIS, (uint64_t)n_nee);
+            if (loop) hipLaunchKernelGGL(k_mis<true>, dim3(nblocks(n_nee)), dim3(TPB), 0, s, ctx->sc, ctx->pipe, n_nee, (const int *)q_nee, ctx->ctrs);
+            else hipLaunchKernelGGL(k_mis<false>, dim3(nblocks(n_nee)), dim3(TPB), 0, s, ctx->sc, ctx->pipe, n_nee, (const int *)q_nee, ctx->ctrs);
         }
         q_cur = q_next;
         n_cur = n_next;
@@ -698,7 +738,7 @@ int ptr_generate_rays(PtrContext *ctx, int sample, float *d_o, float *d_d, float
     prm.npix = ctx->npix;
     prm.width = ctx->width;
     prm.height = ctx->height;
-    ProfScope ps(ctx, K_API_RAYGEN, (uint64_t)ctx->npix);
+    ProfScope ps(ctx, K_RAYGEN, (uint64_t)ctx->npix);
     hipLaunchKernelGGL(k_raygen_only, dim3(nblocks(ctx->npix)), dim3(TPB), 0, ctx->stream, ctx->cam, prm, sample, d_o, d_d, d_weight);
     HIPCHK(hipGetLastError());
     return PTR_OK;
