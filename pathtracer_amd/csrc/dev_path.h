@@ -62,7 +62,10 @@ struct __attribute__((aligned(16))) NeeRec {
     float fB[3], wB, pdfB;
     float oB[3], dB[3];
     int medB, light;
-    int pad[2];
+    /* results of the two queued scene queries (persistent tracer), read by the resolve kernel */
+    int occA, hitB;
+    float tB;
+    int pad[3];
 };
 
 PD void st3(float *d, const f3 &v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; }
@@ -435,6 +438,46 @@ PD f3 nee_mis_resolve(const DScene &sc, const NeeRec &rec, NeeCtr &ctr, const La
         if (!is_black(Li2)) Ld += ld3(rec.fB) * Li2 * Tr * rec.wB / rec.pdfB;
     }
     /* UniformSampleOneLight: / lightPdf with lightPdf = 1 / nLights, primitive.cpp:341-358 */
+    float selPdf = float(1) / sc.n_lights;
+    f3 uL = Ld / selPdf;
+    f3 out = ld3(rec.beta) * uL;
+    if ((rec.flags & NEE_COUNT_ZERO) && is_black(out)) ctr.zero++;
+    return out;
+}
+
+/* Both stages for the case where the walks cannot go past their first hit (see nee_shadow): the
+ * any-hit result of the shadow ray (rec.occA) and the closest hit of the MIS ray (rec.hitB, rec.tB)
+ * were produced by the persistent tracer. */
+PD f3 nee_resolve_traced(const DScene &sc, const NeeRec &rec, NeeCtr &ctr) {
+    f3 Ld(0.f);
+    const bool medium = (rec.flags & NEE_MEDIUM) != 0;
+    if (rec.flags & NEE_A) {
+        f3 Li = ld3(rec.LiA);
+        ctr.shadow++;
+        if (rec.occA) Li = f3(0.f);
+        else if (medium) {
+            f3 Tr(1.f);
+            if (rec.medA >= 0) Tr *= medium_tr(sc.media[rec.medA], ld3(rec.dA), 1 - kShadowEpsilon);
+            Li *= Tr;
+        }
+        if (!is_black(Li)) Ld += ld3(rec.fA) * Li * rec.wA / rec.pdfA;
+    }
+    if (rec.flags & NEE_B) {
+        f3 Tr(1.f);
+        f3 rd = ld3(rec.dB);
+        int hp = rec.hitB;
+        bool found = hp >= 0;
+        ctr.mis++;
+        if (medium) {
+            if (rec.medB >= 0) Tr *= medium_tr(sc.media[rec.medB], rd, rec.tB);
+            if (found && (sc.prims[hp].flags & PF_EMISSIVE)) found = false;
+        }
+        f3 Li2(0.f);
+        if (found) {
+            if (sc.prims[hp].light == rec.light) Li2 = surface_le(sc, hp);
+        } else Li2 = light_le(sc, sc.lights[rec.light], rd);
+        if (!is_black(Li2)) Ld += ld3(rec.fB) * Li2 * Tr * rec.wB / rec.pdfB;
+    }
     float selPdf = float(1) / sc.n_lights;
     f3 uL = Ld / selPdf;
     f3 out = ld3(rec.beta) * uL;

@@ -1,0 +1,239 @@
+/*
+ * dev_trace.h — persistent-wavefront ray tracer: the scene query of Aggregator::Intersect
+ * (primitive.cpp:374-431) for a queue of rays, with the per-ray logic of traverse<>() in
+ * dev_isect.h unrolled into a per-lane state machine.
+ *
+ * Why: ray cost on this path is heavy-tailed (config[1]: median 4 box tests, mean 11-27, 99.9th
+ * percentile ~700, maximum ~1500; a wavefront that keeps its 64 rays until the last one ends
+ * spends ~20x the mean).  Here a wavefront is persistent: a lane whose ray has ended takes the
+ * next ray from the queue (64 indices per atomic, handed out by ballot rank), so a long ray
+ * occupies one lane, not a wavefront.  Each ray still sees exactly the operations of traverse<>:
+ * top level = the reference's own primitive BVH walked in its order, geometry level = SAH BVH,
+ * near child first, closest-hit rule t <= tMax.
+ */
+#pragma once
+#include "dev_isect.h"
+
+struct TraceIO {
+    const int *queue; /* ray slots, or null for identity */
+    int n;
+    /* ray origin / direction: component c of slot s at base + s*es + c*cs (bytes): SoA planes or AoS */
+    const char *o, *d;
+    long long o_es, o_cs, d_es, d_cs;
+    const char *tmax; /* per-slot float, or null: tmax_const */
+    long long tmax_es;
+    float tmax_const;
+    /* outputs, any may be null.  Closest: prim (-1 = miss), face, t (tmax passes through on a
+     * miss), b0, b1.  ANY: prim receives 1 / 0 (occluded or not). */
+    char *prim, *face, *t, *b0, *b1;
+    long long prim_es, face_es, t_es, b0_es, b1_es;
+    int *counter; /* ray-fetch cursor, zero at launch */
+};
+
+enum { TM_IDLE = 0, TM_TOP = 1, TM_TOPLEAF = 2, TM_GEOM = 3 };
+
+#define PT_PUSH(v)                                          \
+    do {                                                    \
+        if (sp < LDS_STACK) lds[sp * TRACE_TPB] = (v);      \
+        else if (sp < BVH_STACK) ovf[sp - LDS_STACK] = (v); \
+        sp++;                                               \
+    } while (0)
+#define PT_POP() (--sp, sp < LDS_STACK ? lds[sp * TRACE_TPB] : ovf[(sp < BVH_STACK ? sp : BVH_STACK - 1) - LDS_STACK])
+
+/* inner loops hand control back (to let finished lanes refill) once this few lanes remain in them */
+#define PT_MIN_ACTIVE 20
+
+template <bool ANY, bool COUNT>
+PD void persistent_trace(const DScene &sc, const TraceIO &io, int *lds, unsigned *total_nodes, unsigned *total_items) {
+    int ovf[OVF_STACK];
+    const int lane = __lane_id();
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+    int mode = TM_IDLE, slot = -1;
+    f3 ro, rd, inv;
+    TriRay tr;
+    tr.kx = tr.ky = tr.kz = 0; tr.Sx = tr.Sy = tr.Sz = 0;
+    float tmax = 0, hb0 = 0, hb1 = 0;
+    int hp = -1, hf = -1;
+    bool hit = false;
+    int tnode = -1, leaf_pos = 0, leaf_end = 0, cp = -1, node = 0, sp = 0, sp_base = 0;
+    unsigned rn = 0, ri = 0; /* per-ray work (COUNT) */
+
+    int pool_pos = 0, pool_end = 0; /* wave-uniform */
+    bool exhausted = false;
+
+#define PT_FINISH()                                                                             \
+    do {                                                                                        \
+        if (ANY) {                                                                              \
+            if (io.prim) *(int *)(io.prim + (long long)slot * io.prim_es) = hit ? 1 : 0;        \
+        } else {                                                                                \
+            if (io.prim) *(int *)(io.prim + (long long)slot * io.prim_es) = hit ? hp : -1;      \
+            if (io.face) *(int *)(io.face + (long long)slot * io.face_es) = hit ? hf : -1;      \
+            if (io.t) *(float *)(io.t + (long long)slot * io.t_es) = tmax;                      \
+            if (COUNT && io.b0 && io.b1) {                                                      \
+                *(float *)(io.b0 + (long long)slot * io.b0_es) = (float)rn;                     \
+                *(float *)(io.b1 + (long long)slot * io.b1_es) = (float)ri;                     \
+            } else {                                                                            \
+                if (io.b0) *(float *)(io.b0 + (long long)slot * io.b0_es) = hit ? hb0 : 0;      \
+                if (io.b1) *(float *)(io.b1 + (long long)slot * io.b1_es) = hit ? hb1 : 0;      \
+            }                                                                                   \
+        }                                                                                       \
+        if (COUNT) { *total_nodes += rn; *total_items += ri; }                                  \
+        mode = TM_IDLE;                                                                         \
+        slot = -1;                                                                              \
+    } while (0)
+
+    for (;;) {
+        /* ---- refill idle lanes ---- */
+        unsigned long long idle = __ballot(mode == TM_IDLE);
+        if (idle) {
+            if (pool_pos >= pool_end && !exhausted) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(io.counter, 64);
+                base = __shfl(base, 0, 64);
+                if (base >= io.n) exhausted = true;
+                else {
+                    pool_pos = base;
+                    pool_end = base + 64 < io.n ? base + 64 : io.n;
+                }
+            }
+            const int avail = pool_end - pool_pos;
+            if (avail > 0) {
+                const int rank = __popcll(idle & lt_mask);
+                if (mode == TM_IDLE && rank < avail) {
+                    const int idx = pool_pos + rank;
+                    slot = io.queue ? io.queue[idx] : idx;
+                    const char *po = io.o + (long long)slot * io.o_es;
+                    const char *pd = io.d + (long long)slot * io.d_es;
+                    ro = f3(*(const float *)po, *(const float *)(po + io.o_cs), *(const float *)(po + 2 * io.o_cs));
+                    rd = f3(*(const float *)pd, *(const float *)(pd + io.d_cs), *(const float *)(pd + 2 * io.d_cs));
+                    tmax = io.tmax ? *(const float *)(io.tmax + (long long)slot * io.tmax_es) : io.tmax_const;
+                    inv = f3(1 / rd.x, 1 / rd.y, 1 / rd.z);
+                    tr = tri_ray_setup(rd);
+                    hp = -1; hf = -1; hb0 = 0; hb1 = 0; hit = false;
+                    rn = 0; ri = 0;
+                    sp = 0;
+                    if (sc.n_top == 0) PT_FINISH();
+                    else {
+                        PT_PUSH(-1);
+                        tnode = 0;
+                        mode = TM_TOP;
+                    }
+                }
+                const int want = __popcll(idle);
+                pool_pos += want < avail ? want : avail;
+            }
+            if (exhausted && __ballot(mode != TM_IDLE) == 0) break; /* every wave reaches this: the grid drains */
+        }
+
+        /* ---- top level: the reference's own tree, step for step (primitive.cpp:374-431) ---- */
+        while (mode == TM_TOP || mode == TM_TOPLEAF) {
+            if (mode == TM_TOP) {
+                if (tnode == -1) { PT_FINISH(); break; }
+                const TopNode &nd = sc.top[tnode];
+                float te;
+                if (COUNT) rn += 1;
+                if (slab_test(nd.bmin, nd.bmax, ro, inv, tmax, &te)) {
+                    if (nd.left < 0) {
+                        leaf_pos = nd.first;
+                        leaf_end = nd.first + nd.n;
+                        mode = TM_TOPLEAF;
+                    } else {
+                        const TopNode &l = sc.top[nd.left];
+                        const TopNode &r = sc.top[nd.right];
+                        float tl0, tr0;
+                        if (COUNT) rn += 2;
+                        bool visitL = slab_test(l.bmin, l.bmax, ro, inv, tmax, &tl0);
+                        bool visitR = slab_test(r.bmin, r.bmax, ro, inv, tmax, &tr0);
+                        if (visitR && visitL) {
+                            int first, second;
+                            if (tr0 < tl0) { first = nd.right; second = nd.left; }
+                            else { first = nd.left; second = nd.right; }
+                            PT_PUSH(second);
+                            tnode = first;
+                        } else if (visitL) tnode = nd.left;
+                        else if (visitR) tnode = nd.right;
+                        else tnode = PT_POP();
+                    }
+                } else tnode = PT_POP();
+            } else {
+                if (leaf_pos == leaf_end) {
+                    tnode = PT_POP();
+                    mode = TM_TOP;
+                } else {
+                    const int p = sc.order[leaf_pos++];
+                    const DPrim &pr = sc.prims[p];
+                    if (pr.type == SH_MESH || pr.type == SH_CLOUD) {
+                        cp = p;
+                        node = pr.root;
+                        sp_base = sp;
+                        mode = TM_GEOM;
+                    } else {
+                        float t;
+                        int face;
+                        if (COUNT) ri += 1;
+                        if (shape_hit_t(pr, ro, rd, tmax, &t, &face)) {
+                            tmax = t; hp = p; hf = face; hb0 = 0; hb1 = 0; hit = true;
+                            if (ANY) { PT_FINISH(); break; }
+                        }
+                    }
+                }
+            }
+        }
+
+        /* ---- geometry level: inner nodes until a leaf ---- */
+        while (mode == TM_GEOM && node >= 0) {
+            const float4 *np = reinterpret_cast<const float4 *>(sc.nodes + node);
+            float4 a = np[0], b = np[1], c = np[2], d = np[3];
+            float lmin[3] = {a.x, a.y, a.z}, lmax[3] = {a.w, b.x, b.y};
+            float rmin[3] = {b.z, b.w, c.x}, rmax[3] = {c.y, c.z, c.w};
+            int left = __float_as_int(d.x), right = __float_as_int(d.y);
+            float tl, tr0;
+            bool hl = slab_test(lmin, lmax, ro, inv, tmax, &tl);
+            bool hr = slab_test(rmin, rmax, ro, inv, tmax, &tr0);
+            if (COUNT) rn += 2;
+            if (hl && hr) {
+                int first = left, second = right;
+                if (tr0 < tl) { first = right; second = left; }
+                PT_PUSH(second);
+                node = first;
+            } else if (hl) node = left;
+            else if (hr) node = right;
+            else if (sp == sp_base) mode = TM_TOPLEAF;
+            else node = PT_POP();
+            if (__popcll(__ballot(mode == TM_GEOM && node >= 0)) < PT_MIN_ACTIVE) break;
+        }
+
+        /* ---- leaf ---- */
+        if (mode == TM_GEOM && node < 0) {
+            unsigned packed = (unsigned)(-(node + 1));
+            unsigned first = packed & 0x07FFFFFFu, n = (packed >> 27) + 1;
+            bool ended = false;
+            for (unsigned i = 0; i < n; i++) {
+                const float4 *ip = reinterpret_cast<const float4 *>(sc.items + first + i);
+                float4 q0 = ip[0], q1 = ip[1], q2 = ip[2];
+                int kind = __float_as_int(q2.w);
+                if (COUNT) ri += 1;
+                if (kind == ITEM_TRI) {
+                    float t, b0, b1, b2;
+                    if (tri_hit_pre(ro, tr, tmax, f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), &t, &b0, &b1, &b2)) {
+                        tmax = t; hp = cp; hf = __float_as_int(q1.w); hb0 = b0; hb1 = b1; hit = true;
+                        if (ANY) { ended = true; break; }
+                    }
+                } else {
+                    f3 o, dd;
+                    particle_object_ray(ro, rd, f3(q0.x, q0.y, q0.z), &o, &dd);
+                    float t;
+                    if (sphere_hit_t_obj(o, dd, q1.x, tmax, &t)) {
+                        tmax = t; hp = cp; hf = __float_as_int(q1.w); hb0 = 0; hb1 = 0; hit = true;
+                        if (ANY) { ended = true; break; }
+                    }
+                }
+            }
+            if (ended) PT_FINISH();
+            else if (sp == sp_base) mode = TM_TOPLEAF;
+            else node = PT_POP();
+        }
+    }
+#undef PT_FINISH
+}

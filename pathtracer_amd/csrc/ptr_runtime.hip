@@ -10,8 +10,11 @@
  * wavefronts and small per-lane state.
  */
 #include "dev_path.h"
+#include "dev_trace.h"
 #include "ptr_host.h"
 #include <hip/hip_runtime.h>
+#include <cfloat>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -126,64 +129,25 @@ __global__ void __launch_bounds__(TPB) k_raygen_only(DCamera cam, PassParams prm
     if (w_out) w_out[p] = w;
 }
 
-/* Aggregator::Intersect over a batch: rays in SoA planes with plane stride `stride`; `queue`
- * (optional) lists the ray slots to trace.  Outputs are indexed by slot. */
-template <bool COUNT>
-__global__ void __launch_bounds__(TPB) k_trace_closest(DScene sc, int n, const int *queue, int stride, const float *o, const float *d,
-                                                       const float *tmax_in, int *hprim, int *hface, float *ht, float *hb0, float *hb1,
-                                                       unsigned long long *ctrs) {
+/* Aggregator::Intersect (ANY = false) / VisibilityTester::Unoccluded (ANY = true) over a queue of
+ * rays: persistent wavefronts, see dev_trace.h */
+template <bool ANY, bool COUNT>
+__global__ void __launch_bounds__(TRACE_TPB) k_ptrace(DScene sc, TraceIO io, unsigned long long *ctrs) {
     __shared__ int s_stack[LDS_STACK * TRACE_TPB];
-    LaneStack ls;
-    ls.lds = &s_stack[threadIdx.x];
-    int i = blockIdx.x * TPB + threadIdx.x;
-    TraceStats st;
-    st.nodes = 0;
-    st.items = 0;
-    if (i < n) {
-        int slot = queue ? queue[i] : i;
-        f3 ro(o[slot], o[stride + slot], o[2 * stride + slot]);
-        f3 rd(d[slot], d[stride + slot], d[2 * stride + slot]);
-        float tmax = tmax_in ? tmax_in[slot] : kInfinity;
-        int hp = -1, hf = -1;
-        float b0 = 0, b1 = 0;
-        bool hit = traverse<false, COUNT>(sc, ro, rd, tmax, hp, hf, b0, b1, &st, ls);
-        hprim[slot] = hit ? hp : -1;
-        hface[slot] = hit ? hf : -1;
-        ht[slot] = tmax;
-        if (COUNT && hb0 && hb1) { /* profiling: per-ray work instead of barycentrics (ptr_profile_enable bit 1) */
-            hb0[slot] = (float)st.nodes;
-            hb1[slot] = (float)st.items;
-        } else {
-            if (hb0) hb0[slot] = hit ? b0 : 0;
-            if (hb1) hb1[slot] = hit ? b1 : 0;
-        }
-    }
+    unsigned tn = 0, ti = 0;
+    persistent_trace<ANY, COUNT>(sc, io, &s_stack[threadIdx.x], &tn, &ti);
     if (COUNT) {
-        ctr_flush(ctrs, C_NODES, st.nodes);
-        ctr_flush(ctrs, C_PRIMS, st.items);
+        ctr_flush(ctrs, C_NODES, tn);
+        ctr_flush(ctrs, C_PRIMS, ti);
     }
-}
-
-__global__ void __launch_bounds__(TPB) k_trace_occluded(DScene sc, int n, const float *o, const float *d, const float *tmax_in, int *occ) {
-    __shared__ int s_stack[LDS_STACK * TRACE_TPB];
-    LaneStack ls;
-    ls.lds = &s_stack[threadIdx.x];
-    int i = blockIdx.x * TPB + threadIdx.x;
-    if (i >= n) return;
-    f3 ro(o[i], o[n + i], o[2 * n + i]);
-    f3 rd(d[i], d[n + i], d[2 * n + i]);
-    float tmax = tmax_in ? tmax_in[i] : kInfinity;
-    int hp = -1, hf = -1;
-    float b0, b1;
-    occ[i] = traverse<true, false>(sc, ro, rd, tmax, hp, hf, b0, b1, nullptr, ls) ? 1 : 0;
 }
 
 __global__ void __launch_bounds__(TPB) k_shade(DScene sc, Pipe pp, PassParams prm, int n, const int *queue, int *q_next, int *q_nee,
-                                               int *q_shadow, int *counts, unsigned long long *ctrs) {
+                                               int *q_shadow, int *q_mis, int *counts, unsigned long long *ctrs) {
     int i = blockIdx.x * TPB + threadIdx.x;
     VertexCtr ctr;
     ctr.total = ctr.miss = ctr.surf = ctr.med = ctr.light = ctr.zero = 0;
-    bool alive = false, want_nee = false, want_shadow = false;
+    bool alive = false, want_nee = false, want_shadow = false, want_mis = false;
     int slot = 0;
     if (i < n) {
         slot = queue ? queue[i] : i;
@@ -202,6 +166,7 @@ __global__ void __launch_bounds__(TPB) k_shade(DScene sc, Pipe pp, PassParams pr
         alive = vo.alive;
         want_nee = vo.want_nee;
         want_shadow = want_nee && (pp.nee[slot].flags & NEE_A);
+        want_mis = want_nee && (pp.nee[slot].flags & NEE_B);
         st3(ps.L, L);
         st3(ps.beta, beta);
         ps.medium = med;
@@ -217,6 +182,7 @@ __global__ void __launch_bounds__(TPB) k_shade(DScene sc, Pipe pp, PassParams pr
     queue_append(&counts[0], q_next, alive, slot);
     queue_append(&counts[1], q_nee, want_nee, slot);
     queue_append(&counts[2], q_shadow, want_shadow, slot);
+    queue_append(&counts[3], q_mis, want_mis, slot);
     ctr_flush(ctrs, C_TOTAL, ctr.total);
     ctr_flush(ctrs, C_MISS, ctr.miss);
     ctr_flush(ctrs, C_SURF, ctr.surf);
@@ -257,6 +223,24 @@ __global__ void __launch_bounds__(TPB) k_mis(DScene sc, Pipe pp, int n, const in
     ctr_flush(ctrs, C_ZERO, ctr.zero);
 }
 
+/* sum of a direct-light record whose two rays went through the persistent tracer */
+__global__ void __launch_bounds__(TPB) k_nee_resolve(DScene sc, Pipe pp, int n, const int *queue, unsigned long long *ctrs) {
+    int i = blockIdx.x * TPB + threadIdx.x;
+    NeeCtr ctr;
+    ctr.shadow = ctr.mis = ctr.zero = 0;
+    if (i < n) {
+        int slot = queue[i];
+        f3 Ld = nee_resolve_traced(sc, pp.nee[slot], ctr);
+        PathRec *ps = &pp.paths[slot];
+        f3 L = ld3(ps->L);
+        L += Ld;
+        st3(ps->L, L);
+    }
+    ctr_flush(ctrs, C_SHADOW, ctr.shadow);
+    ctr_flush(ctrs, C_MIS, ctr.mis);
+    ctr_flush(ctrs, C_ZERO, ctr.zero);
+}
+
 /* Render()'s accumulation (main.cpp:449-455): we += weight * L per sample, in sample order */
 __global__ void __launch_bounds__(TPB) k_film(Pipe pp, int npix, int nbatch, float *we, double *acc, long long *samples) {
     int p = blockIdx.x * TPB + threadIdx.x;
@@ -287,9 +271,9 @@ static int set_err(int code, const std::string &msg) {
         if (e_ != hipSuccess) return set_err(PTR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-enum { K_RAYGEN = 0, K_TRACE, K_SHADE, K_SHADOW, K_MIS, K_FILM, K_API_CLOSEST, K_API_OCCLUDED };
-static const char *kKernelNames[PTR_PROF_KERNELS] = {"raygen", "trace_closest", "shade", "nee_shadow", "nee_mis", "film", "api_trace_closest",
-                                                     "api_trace_occluded"};
+enum { K_RAYGEN = 0, K_TRACE, K_SHADE, K_SHADOW, K_MIS, K_RESOLVE, K_FILM, K_API_TRACE };
+static const char *kKernelNames[PTR_PROF_KERNELS] = {"raygen", "trace_closest", "shade", "nee_shadow", "nee_mis", "nee_resolve", "film",
+                                                     "api_trace"};
 
 struct ProfSpan {
     hipEvent_t a, b;
@@ -315,8 +299,11 @@ struct PtrContext {
     int sample_cursor = 0, shard_offset = 0, shard_stride = 1;
     /* pipeline */
     Pipe pipe;
-    int *queues[4] = {nullptr, nullptr, nullptr, nullptr};
-    int *counts = nullptr;      /* device: [0] next, [1] nee, [2] shadow */
+    int *queues[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int *counts = nullptr;      /* device: [0] next, [1] nee, [2] shadow, [3] mis */
+    int *fetch = nullptr;       /* ray-fetch cursors of the persistent tracer (rotating) */
+    int fetch_next = 0;
+    int persist_blocks = 1024;
     int *counts_host = nullptr; /* pinned */
     int nb_max = 1;
     unsigned long long *ctrs = nullptr;
@@ -352,13 +339,13 @@ static void free_scene(PtrContext *ctx) {
 }
 static void free_film(PtrContext *ctx) {
     void *ptrs[] = {ctx->we, ctx->acc, ctx->samples, ctx->pipe.ro, ctx->pipe.rd, ctx->pipe.hprim, ctx->pipe.hface, ctx->pipe.ht,
-                    ctx->pipe.paths, ctx->pipe.nee, ctx->queues[0], ctx->queues[1], ctx->queues[2], ctx->queues[3], ctx->counts};
+                    ctx->pipe.paths, ctx->pipe.nee, ctx->queues[0], ctx->queues[1], ctx->queues[2], ctx->queues[3], ctx->queues[4], ctx->counts};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (ctx->counts_host) (void)hipHostFree(ctx->counts_host);
     ctx->we = nullptr; ctx->acc = nullptr; ctx->samples = nullptr;
     memset(&ctx->pipe, 0, sizeof(ctx->pipe));
-    ctx->queues[0] = ctx->queues[1] = ctx->queues[2] = ctx->queues[3] = nullptr;
+    ctx->queues[0] = ctx->queues[1] = ctx->queues[2] = ctx->queues[3] = ctx->queues[4] = nullptr;
     ctx->counts = nullptr;
     ctx->counts_host = nullptr;
     ctx->has_film = false;
@@ -401,6 +388,34 @@ static void prof_drain(PtrContext *ctx) {
 
 static inline unsigned nblocks(int n) { return (unsigned)((n + TPB - 1) / TPB); }
 
+#define FETCH_SLOTS 256
+/* one launch of the persistent tracer over io.n rays */
+static int launch_ptrace(PtrContext *ctx, TraceIO io, bool any, bool count, int family) {
+    if (io.n <= 0) return PTR_OK;
+    io.counter = ctx->fetch + (ctx->fetch_next++ % FETCH_SLOTS);
+    HIPCHK(hipMemsetAsync(io.counter, 0, sizeof(int), ctx->stream));
+    unsigned blocks = nblocks(io.n);
+    if (blocks > (unsigned)ctx->persist_blocks) blocks = (unsigned)ctx->persist_blocks;
+    ProfScope ps(ctx, family, (uint64_t)io.n);
+    if (any) hipLaunchKernelGGL((k_ptrace<true, false>), dim3(blocks), dim3(TRACE_TPB), 0, ctx->stream, ctx->sc, io, ctx->ctrs);
+    else if (count) hipLaunchKernelGGL((k_ptrace<false, true>), dim3(blocks), dim3(TRACE_TPB), 0, ctx->stream, ctx->sc, io, ctx->ctrs);
+    else hipLaunchKernelGGL((k_ptrace<false, false>), dim3(blocks), dim3(TRACE_TPB), 0, ctx->stream, ctx->sc, io, ctx->ctrs);
+    return PTR_OK;
+}
+static TraceIO soa_io(int n, const int *queue, long long plane, const float *o, const float *d, const float *tmax, int *prim, int *face,
+                      float *t, float *b0, float *b1) {
+    TraceIO io;
+    memset(&io, 0, sizeof(io));
+    io.queue = queue;
+    io.n = n;
+    io.o = (const char *)o; io.o_es = 4; io.o_cs = 4 * plane;
+    io.d = (const char *)d; io.d_es = 4; io.d_cs = 4 * plane;
+    io.tmax = (const char *)tmax; io.tmax_es = 4; io.tmax_const = FLT_MAX;
+    io.prim = (char *)prim; io.face = (char *)face; io.t = (char *)t; io.b0 = (char *)b0; io.b1 = (char *)b1;
+    io.prim_es = io.face_es = io.t_es = io.b0_es = io.b1_es = 4;
+    return io;
+}
+
 extern "C" {
 
 const char *ptr_last_error(void) { return g_err.c_str(); }
@@ -430,6 +445,13 @@ int ptr_create(int device, PtrContext **out) {
         return set_err(PTR_ERR_HIP, "hipMalloc(counters) failed");
     }
     (void)hipMemset(ctx->ctrs, 0, C_COUNT * sizeof(unsigned long long));
+    if (hipMalloc((void **)&ctx->fetch, FETCH_SLOTS * sizeof(int)) != hipSuccess) {
+        (void)hipFree(ctx->ctrs);
+        delete ctx;
+        return set_err(PTR_ERR_HIP, "hipMalloc(fetch cursors) failed");
+    }
+    /* persistent grid: enough 256-thread blocks to fill every CU at the tracer's occupancy */
+    ctx->persist_blocks = prop.multiProcessorCount * 4;
     *out = ctx;
     return PTR_OK;
 }
@@ -443,6 +465,7 @@ int ptr_destroy(PtrContext *ctx) {
     free_scene(ctx);
     free_film(ctx);
     if (ctx->ctrs) (void)hipFree(ctx->ctrs);
+    if (ctx->fetch) (void)hipFree(ctx->fetch);
     delete ctx;
     return PTR_OK;
 }
@@ -564,7 +587,7 @@ int ptr_film_init(PtrContext *ctx, int width, int height, uint64_t seed) {
         HIPCHK(hipMalloc((void **)&ctx->pipe.ht, sizeof(float) * cap));
         HIPCHK(hipMalloc((void **)&ctx->pipe.paths, sizeof(PathRec) * cap));
         HIPCHK(hipMalloc((void **)&ctx->pipe.nee, sizeof(NeeRec) * cap));
-        for (int q = 0; q < 4; q++) HIPCHK(hipMalloc((void **)&ctx->queues[q], sizeof(int) * cap));
+        for (int q = 0; q < 5; q++) HIPCHK(hipMalloc((void **)&ctx->queues[q], sizeof(int) * cap));
         HIPCHK(hipMalloc((void **)&ctx->counts, 4 * sizeof(int)));
         HIPCHK(hipHostMalloc((void **)&ctx->counts_host, 4 * sizeof(int), hipHostMallocDefault));
         ctx->pipe.cap = (int)cap;
@@ -611,39 +634,63 @@ static int run_pass(PtrContext *ctx, int first, int step, int nb, int integrator
     int qi = 0;
     for (int iter = 0; n_cur > 0 && iter < 4096; iter++) {
         int *q_next = ctx->queues[qi];
-        int *q_nee = ctx->queues[2], *q_shadow = ctx->queues[3];
+        int *q_nee = ctx->queues[2], *q_shadow = ctx->queues[3], *q_mis = ctx->queues[4];
         HIPCHK(hipMemsetAsync(ctx->counts, 0, 4 * sizeof(int), s));
         {
-            ProfScope ps(ctx, K_TRACE, (uint64_t)n_cur);
-            if (ctx->count_traversal)
-                hipLaunchKernelGGL(k_trace_closest<true>, dim3(nblocks(n_cur)), dim3(TPB), 0, s, ctx->sc, n_cur, q_cur, ctx->pipe.cap,
-                                   ctx->pipe.ro, ctx->pipe.rd, (const float *)nullptr, ctx->pipe.hprim, ctx->pipe.hface, ctx->pipe.ht,
-                                   (float *)nullptr, (float *)nullptr, ctx->ctrs);
-            else
-                hipLaunchKernelGGL(k_trace_closest<false>, dim3(nblocks(n_cur)), dim3(TPB), 0, s, ctx->sc, n_cur, q_cur, ctx->pipe.cap,
-                                   ctx->pipe.ro, ctx->pipe.rd, (const float *)nullptr, ctx->pipe.hprim, ctx->pipe.hface, ctx->pipe.ht,
-                                   (float *)nullptr, (float *)nullptr, ctx->ctrs);
+            TraceIO io = soa_io(n_cur, q_cur, ctx->pipe.cap, ctx->pipe.ro, ctx->pipe.rd, nullptr, ctx->pipe.hprim, ctx->pipe.hface,
+                                ctx->pipe.ht, nullptr, nullptr);
+            int rc = launch_ptrace(ctx, io, false, ctx->count_traversal, K_TRACE);
+            if (rc) return rc;
         }
         {
             ProfScope ps(ctx, K_SHADE, (uint64_t)n_cur);
             hipLaunchKernelGGL(k_shade, dim3(nblocks(n_cur)), dim3(TPB), 0, s, ctx->sc, ctx->pipe, prm, n_cur, q_cur, q_next, q_nee, q_shadow,
-                               ctx->counts, ctx->ctrs);
+                               q_mis, ctx->counts, ctx->ctrs);
         }
         HIPCHK(hipMemcpyAsync(ctx->counts_host, ctx->counts, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
-        int n_next = ctx->counts_host[0], n_nee = ctx->counts_host[1], n_shadow = ctx->counts_host[2];
+        int n_next = ctx->counts_host[0], n_nee = ctx->counts_host[1], n_shadow = ctx->counts_host[2], n_mis = ctx->counts_host[3];
         /* the walks of VisibilityTester::Tr / IntersectTr can only go past their first hit under
          * Li_VolPath and only if some primitive has no material (medium boundary, emitter) */
         const bool loop = integrator == PTR_LI_VOLPATH && !ctx->scene_all_opaque;
-        if (n_shadow > 0) {
-            ProfScope ps(ctx, K_SHADOW, (uint64_t)n_shadow);
-            if (loop) hipLaunchKernelGGL(k_shadow<true>, dim3(nblocks(n_shadow)), dim3(TPB), 0, s, ctx->sc, ctx->pipe, n_shadow, (const int *)q_shadow, ctx->ctrs);
-            else hipLaunchKernelGGL(k_shadow<false>, dim3(nblocks(n_shadow)), dim3(TPB), 0, s, ctx->sc, ctx->pipe, n_shadow, (const int *)q_shadow, ctx->ctrs);
-        }
-        if (n_nee > 0) {
-            ProfScope ps(ctx, K_MIS, (uint64_t)n_nee);
-            if (loop) hipLaunchKernelGGL(k_mis<true>, dim3(nblocks(n_nee)), dim3(TPB), 0, s, ctx->sc, ctx->pipe, n_nee, (const int *)q_nee, ctx->ctrs);
-            else hipLaunchKernelGGL(k_mis<false>, dim3(nblocks(n_nee)), dim3(TPB), 0, s, ctx->sc, ctx->pipe, n_nee, (const int *)q_nee, ctx->ctrs);
+        if (loop) {
+            if (n_shadow > 0) {
+                ProfScope ps(ctx, K_SHADOW, (uint64_t)n_shadow);
+                hipLaunchKernelGGL(k_shadow<true>, dim3(nblocks(n_shadow)), dim3(TPB), 0, s, ctx->sc, ctx->pipe, n_shadow, (const int *)q_shadow, ctx->ctrs);
+            }
+            if (n_nee > 0) {
+                ProfScope ps(ctx, K_MIS, (uint64_t)n_nee);
+                hipLaunchKernelGGL(k_mis<true>, dim3(nblocks(n_nee)), dim3(TPB), 0, s, ctx->sc, ctx->pipe, n_nee, (const int *)q_nee, ctx->ctrs);
+            }
+        } else {
+            NeeRec *nee = ctx->pipe.nee;
+            if (n_shadow > 0) { /* shadow rays: any hit within (0, 1 - ShadowEpsilon) */
+                TraceIO io;
+                memset(&io, 0, sizeof(io));
+                io.queue = q_shadow; io.n = n_shadow;
+                io.o = (const char *)nee + offsetof(NeeRec, oA); io.o_es = sizeof(NeeRec); io.o_cs = 4;
+                io.d = (const char *)nee + offsetof(NeeRec, dA); io.d_es = sizeof(NeeRec); io.d_cs = 4;
+                io.tmax_const = 1 - 0.0001f;
+                io.prim = (char *)nee + offsetof(NeeRec, occA); io.prim_es = sizeof(NeeRec);
+                int rc = launch_ptrace(ctx, io, true, false, K_SHADOW);
+                if (rc) return rc;
+            }
+            if (n_mis > 0) { /* MIS rays: closest hit */
+                TraceIO io;
+                memset(&io, 0, sizeof(io));
+                io.queue = q_mis; io.n = n_mis;
+                io.o = (const char *)nee + offsetof(NeeRec, oB); io.o_es = sizeof(NeeRec); io.o_cs = 4;
+                io.d = (const char *)nee + offsetof(NeeRec, dB); io.d_es = sizeof(NeeRec); io.d_cs = 4;
+                io.tmax_const = FLT_MAX;
+                io.prim = (char *)nee + offsetof(NeeRec, hitB); io.prim_es = sizeof(NeeRec);
+                io.t = (char *)nee + offsetof(NeeRec, tB); io.t_es = sizeof(NeeRec);
+                int rc = launch_ptrace(ctx, io, false, false, K_MIS);
+                if (rc) return rc;
+            }
+            if (n_nee > 0) {
+                ProfScope ps(ctx, K_RESOLVE, (uint64_t)n_nee);
+                hipLaunchKernelGGL(k_nee_resolve, dim3(nblocks(n_nee)), dim3(TPB), 0, s, ctx->sc, ctx->pipe, n_nee, (const int *)q_nee, ctx->ctrs);
+            }
         }
         q_cur = q_next;
         n_cur = n_next;
@@ -751,13 +798,11 @@ int ptr_trace_closest(PtrContext *ctx, int n, const float *d_o, const float *d_d
     if (!ctx->has_scene) return set_err(PTR_ERR_STATE, "no scene uploaded");
     if (n < 0 || (n > 0 && (!d_o || !d_d || !d_prim || !d_face || !d_t))) return set_err(PTR_ERR_INVALID, "bad ray batch");
     if (n == 0) return PTR_OK;
-    ProfScope ps(ctx, K_API_CLOSEST, (uint64_t)n);
-    if (ctx->count_traversal)
-        hipLaunchKernelGGL(k_trace_closest<true>, dim3(nblocks(n)), dim3(TPB), 0, ctx->stream, ctx->sc, n, (const int *)nullptr, n, d_o, d_d,
-                           d_tmax, d_prim, d_face, d_t, d_b0, d_b1, ctx->ctrs);
-    else
-        hipLaunchKernelGGL(k_trace_closest<false>, dim3(nblocks(n)), dim3(TPB), 0, ctx->stream, ctx->sc, n, (const int *)nullptr, n, d_o, d_d,
-                           d_tmax, d_prim, d_face, d_t, d_b0, d_b1, ctx->ctrs);
+    {
+        TraceIO io = soa_io(n, nullptr, n, d_o, d_d, d_tmax, d_prim, d_face, d_t, d_b0, d_b1);
+        int rc2 = launch_ptrace(ctx, io, false, ctx->count_traversal, K_API_TRACE);
+        if (rc2) return rc2;
+    }
     HIPCHK(hipGetLastError());
     return PTR_OK;
 }
@@ -768,8 +813,11 @@ int ptr_trace_occluded(PtrContext *ctx, int n, const float *d_o, const float *d_
     if (!ctx->has_scene) return set_err(PTR_ERR_STATE, "no scene uploaded");
     if (n < 0 || (n > 0 && (!d_o || !d_d || !d_occluded))) return set_err(PTR_ERR_INVALID, "bad ray batch");
     if (n == 0) return PTR_OK;
-    ProfScope ps(ctx, K_API_OCCLUDED, (uint64_t)n);
-    hipLaunchKernelGGL(k_trace_occluded, dim3(nblocks(n)), dim3(TPB), 0, ctx->stream, ctx->sc, n, d_o, d_d, d_tmax, d_occluded);
+    {
+        TraceIO io = soa_io(n, nullptr, n, d_o, d_d, d_tmax, d_occluded, nullptr, nullptr, nullptr, nullptr);
+        int rc2 = launch_ptrace(ctx, io, true, false, K_API_TRACE);
+        if (rc2) return rc2;
+    }
     HIPCHK(hipGetLastError());
     return PTR_OK;
 }
