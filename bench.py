@@ -152,7 +152,7 @@ def main():
         bytes_per_ray = 64.0 + 32.0 * nodes_per_ray + 48.0 * items_per_ray
         launches = max(1, tk["launches"])
         avg_ms = tk["total_ms"] / launches
-        rays_per_launch = tk["items"] / launches
+        rays_per_launch = c["total_paths"] / launches  # every path segment is one ray of this kernel
         achieved = bytes_per_ray * rays_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         out = {
             "metric": "Mrays/s (incoherent bounces)",

@@ -17,6 +17,7 @@
 struct TraceIO {
     const int *queue; /* ray slots, or null for identity */
     int n;
+    const int *n_ptr; /* if set, the ray count is read from device memory (written earlier in the stream) */
     /* ray origin / direction: component c of slot s at base + s*es + c*cs (bytes): SoA planes or AoS */
     const char *o, *d;
     long long o_es, o_cs, d_es, d_cs;
@@ -59,6 +60,7 @@ PD void persistent_trace(const DScene &sc, const TraceIO &io, int *lds, unsigned
     int tnode = -1, leaf_pos = 0, leaf_end = 0, cp = -1, node = 0, sp = 0, sp_base = 0;
     unsigned rn = 0, ri = 0; /* per-ray work (COUNT) */
 
+    const int n_rays = io.n_ptr ? *io.n_ptr : io.n;
     int pool_pos = 0, pool_end = 0; /* wave-uniform */
     bool exhausted = false;
 
@@ -91,10 +93,10 @@ PD void persistent_trace(const DScene &sc, const TraceIO &io, int *lds, unsigned
                 int base = 0;
                 if (lane == 0) base = atomicAdd(io.counter, 64);
                 base = __shfl(base, 0, 64);
-                if (base >= io.n) exhausted = true;
+                if (base >= n_rays) exhausted = true;
                 else {
                     pool_pos = base;
-                    pool_end = base + 64 < io.n ? base + 64 : io.n;
+                    pool_end = base + 64 < n_rays ? base + 64 : n_rays;
                 }
             }
             const int avail = pool_end - pool_pos;

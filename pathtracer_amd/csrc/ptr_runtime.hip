@@ -142,11 +142,20 @@ __global__ void __launch_bounds__(TRACE_TPB) k_ptrace(DScene sc, TraceIO io, uns
     }
 }
 
-__global__ void __launch_bounds__(TPB) k_shade(DScene sc, Pipe pp, PassParams prm, int n, const int *queue, int *q_next, int *q_nee,
-                                               int *q_shadow, int *q_mis, int *counts, unsigned long long *ctrs) {
-    int i = blockIdx.x * TPB + threadIdx.x;
+/* grid-stride helper: every lane of a wavefront runs the same number of rounds, so the ballots of
+ * queue_append / ctr_flush stay convergent; n may live in device memory (written by an earlier
+ * kernel of the same stream) */
+#define GRID_STRIDE_BEGIN(n_ptr, n_host)                                                           \
+    const int n = (n_ptr) ? *(n_ptr) : (n_host);                                                   \
+    for (int base_ = blockIdx.x * TPB + (threadIdx.x & ~63); base_ < n; base_ += gridDim.x * TPB) { \
+        const int i = base_ + (threadIdx.x & 63);
+#define GRID_STRIDE_END }
+
+__global__ void __launch_bounds__(TPB) k_shade(DScene sc, Pipe pp, PassParams prm, const int *n_ptr, int n_host, const int *queue,
+                                               int *q_next, int *q_nee, int *q_shadow, int *q_mis, int *counts, unsigned long long *ctrs) {
     VertexCtr ctr;
     ctr.total = ctr.miss = ctr.surf = ctr.med = ctr.light = ctr.zero = 0;
+    GRID_STRIDE_BEGIN(n_ptr, n_host)
     bool alive = false, want_nee = false, want_shadow = false, want_mis = false;
     int slot = 0;
     if (i < n) {
@@ -183,6 +192,7 @@ __global__ void __launch_bounds__(TPB) k_shade(DScene sc, Pipe pp, PassParams pr
     queue_append(&counts[1], q_nee, want_nee, slot);
     queue_append(&counts[2], q_shadow, want_shadow, slot);
     queue_append(&counts[3], q_mis, want_mis, slot);
+    GRID_STRIDE_END
     ctr_flush(ctrs, C_TOTAL, ctr.total);
     ctr_flush(ctrs, C_MISS, ctr.miss);
     ctr_flush(ctrs, C_SURF, ctr.surf);
@@ -191,43 +201,48 @@ __global__ void __launch_bounds__(TPB) k_shade(DScene sc, Pipe pp, PassParams pr
     ctr_flush(ctrs, C_ZERO, ctr.zero);
 }
 
-template <bool LOOP>
-__global__ void __launch_bounds__(TPB) k_shadow(DScene sc, Pipe pp, int n, const int *queue, unsigned long long *ctrs) {
+/* direct-light stages with the walks of VisibilityTester::Tr / IntersectTr (scenes with medium
+ * boundaries or emitters under Li_VolPath) */
+__global__ void __launch_bounds__(TPB) k_shadow_walk(DScene sc, Pipe pp, const int *n_ptr, int n_host, const int *queue,
+                                                     unsigned long long *ctrs) {
     __shared__ int s_stack[LDS_STACK * TRACE_TPB];
     LaneStack ls;
     ls.lds = &s_stack[threadIdx.x];
-    int i = blockIdx.x * TPB + threadIdx.x;
     NeeCtr ctr;
     ctr.shadow = ctr.mis = ctr.zero = 0;
-    if (i < n) nee_shadow<LOOP>(sc, &pp.nee[queue[i]], ctr, ls);
+    GRID_STRIDE_BEGIN(n_ptr, n_host)
+    if (i < n) nee_shadow<true>(sc, &pp.nee[queue[i]], ctr, ls);
+    GRID_STRIDE_END
     ctr_flush(ctrs, C_SHADOW, ctr.shadow);
 }
 
-template <bool LOOP>
-__global__ void __launch_bounds__(TPB) k_mis(DScene sc, Pipe pp, int n, const int *queue, unsigned long long *ctrs) {
+__global__ void __launch_bounds__(TPB) k_mis_walk(DScene sc, Pipe pp, const int *n_ptr, int n_host, const int *queue,
+                                                  unsigned long long *ctrs) {
     __shared__ int s_stack[LDS_STACK * TRACE_TPB];
     LaneStack ls;
     ls.lds = &s_stack[threadIdx.x];
-    int i = blockIdx.x * TPB + threadIdx.x;
     NeeCtr ctr;
     ctr.shadow = ctr.mis = ctr.zero = 0;
+    GRID_STRIDE_BEGIN(n_ptr, n_host)
     if (i < n) {
         int slot = queue[i];
-        f3 Ld = nee_mis_resolve<LOOP>(sc, pp.nee[slot], ctr, ls);
+        f3 Ld = nee_mis_resolve<true>(sc, pp.nee[slot], ctr, ls);
         PathRec *ps = &pp.paths[slot];
         f3 L = ld3(ps->L);
         L += Ld;
         st3(ps->L, L);
     }
+    GRID_STRIDE_END
     ctr_flush(ctrs, C_MIS, ctr.mis);
     ctr_flush(ctrs, C_ZERO, ctr.zero);
 }
 
 /* sum of a direct-light record whose two rays went through the persistent tracer */
-__global__ void __launch_bounds__(TPB) k_nee_resolve(DScene sc, Pipe pp, int n, const int *queue, unsigned long long *ctrs) {
-    int i = blockIdx.x * TPB + threadIdx.x;
+__global__ void __launch_bounds__(TPB) k_nee_resolve(DScene sc, Pipe pp, const int *n_ptr, int n_host, const int *queue,
+                                                     unsigned long long *ctrs) {
     NeeCtr ctr;
     ctr.shadow = ctr.mis = ctr.zero = 0;
+    GRID_STRIDE_BEGIN(n_ptr, n_host)
     if (i < n) {
         int slot = queue[i];
         f3 Ld = nee_resolve_traced(sc, pp.nee[slot], ctr);
@@ -236,6 +251,7 @@ __global__ void __launch_bounds__(TPB) k_nee_resolve(DScene sc, Pipe pp, int n, 
         L += Ld;
         st3(ps->L, L);
     }
+    GRID_STRIDE_END
     ctr_flush(ctrs, C_SHADOW, ctr.shadow);
     ctr_flush(ctrs, C_MIS, ctr.mis);
     ctr_flush(ctrs, C_ZERO, ctr.zero);
@@ -281,13 +297,28 @@ struct ProfSpan {
     uint64_t items;
 };
 
+/* A pass (a batch of samples) owns one lane: its own stream, path-state buffers and queues.
+ * Ray cost is heavy-tailed - a launch over a few hundred late-bounce rays still lasts as long as
+ * its longest ray, ~1 ms of dependent loads - so several passes are kept in flight and the tail
+ * of one overlaps the bulk of the others. */
+#define N_LANES 4
+#define MAX_ITERS 20
+struct Lane {
+    hipStream_t stream = nullptr;
+    Pipe pipe;
+    int *queues[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int *counts = nullptr;      /* device: [MAX_ITERS][4] = next, nee, shadow, mis; then [MAX_ITERS][3] ray-fetch cursors */
+    int *counts_host = nullptr; /* pinned, 4 ints */
+    hipEvent_t film_done = nullptr, joined = nullptr;
+};
+
 struct PtrContext {
     int device = 0;
     hipStream_t stream = nullptr;
     std::vector<void *> scene_allocs;
     DScene sc;
     bool has_scene = false, has_camera = false, has_film = false;
-    bool scene_has_media = false, scene_all_opaque = false;
+    bool scene_has_media = false, scene_all_opaque = false, scene_passthrough = false;
     DCamera cam;
     int64_t bvh_bytes = 0;
     /* film */
@@ -298,13 +329,11 @@ struct PtrContext {
     long long *samples = nullptr;
     int sample_cursor = 0, shard_offset = 0, shard_stride = 1;
     /* pipeline */
-    Pipe pipe;
-    int *queues[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    int *counts = nullptr;      /* device: [0] next, [1] nee, [2] shadow, [3] mis */
-    int *fetch = nullptr;       /* ray-fetch cursors of the persistent tracer (rotating) */
-    int fetch_next = 0;
+    Lane lanes[N_LANES];
+    int next_lane = 0, last_film_lane = -1;
+    int *api_fetch = nullptr; /* ray-fetch cursors of the stand-alone trace entry points (rotating) */
+    int api_fetch_next = 0;
     int persist_blocks = 1024;
-    int *counts_host = nullptr; /* pinned */
     int nb_max = 1;
     unsigned long long *ctrs = nullptr;
     uint64_t camera_rays = 0;
@@ -319,6 +348,13 @@ struct PtrContext {
 static int ctx_use(PtrContext *ctx) {
     if (!ctx) return set_err(PTR_ERR_INVALID, "null context");
     HIPCHK(hipSetDevice(ctx->device));
+    return PTR_OK;
+}
+/* everything this context has in flight, on its lanes and on the caller's stream */
+static int sync_all(PtrContext *ctx) {
+    for (Lane &l : ctx->lanes)
+        if (l.stream) HIPCHK(hipStreamSynchronize(l.stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     return PTR_OK;
 }
 
@@ -338,24 +374,30 @@ static void free_scene(PtrContext *ctx) {
     ctx->has_scene = false;
 }
 static void free_film(PtrContext *ctx) {
-    void *ptrs[] = {ctx->we, ctx->acc, ctx->samples, ctx->pipe.ro, ctx->pipe.rd, ctx->pipe.hprim, ctx->pipe.hface, ctx->pipe.ht,
-                    ctx->pipe.paths, ctx->pipe.nee, ctx->queues[0], ctx->queues[1], ctx->queues[2], ctx->queues[3], ctx->queues[4], ctx->counts};
-    for (void *p : ptrs)
+    void *film[] = {ctx->we, ctx->acc, ctx->samples};
+    for (void *p : film)
         if (p) (void)hipFree(p);
-    if (ctx->counts_host) (void)hipHostFree(ctx->counts_host);
     ctx->we = nullptr; ctx->acc = nullptr; ctx->samples = nullptr;
-    memset(&ctx->pipe, 0, sizeof(ctx->pipe));
-    ctx->queues[0] = ctx->queues[1] = ctx->queues[2] = ctx->queues[3] = ctx->queues[4] = nullptr;
-    ctx->counts = nullptr;
-    ctx->counts_host = nullptr;
+    for (Lane &l : ctx->lanes) {
+        void *ptrs[] = {l.pipe.ro, l.pipe.rd, l.pipe.hprim, l.pipe.hface, l.pipe.ht, l.pipe.paths, l.pipe.nee,
+                        l.queues[0], l.queues[1], l.queues[2], l.queues[3], l.queues[4], l.counts};
+        for (void *p : ptrs)
+            if (p) (void)hipFree(p);
+        if (l.counts_host) (void)hipHostFree(l.counts_host);
+        memset(&l.pipe, 0, sizeof(l.pipe));
+        for (int q = 0; q < 5; q++) l.queues[q] = nullptr;
+        l.counts = nullptr;
+        l.counts_host = nullptr;
+    }
     ctx->has_film = false;
 }
 
 struct ProfScope {
     PtrContext *ctx;
+    hipStream_t stream;
     bool on;
     ProfSpan sp;
-    ProfScope(PtrContext *c, int family, uint64_t items) : ctx(c), on(c->profiling) {
+    ProfScope(PtrContext *c, hipStream_t s, int family, uint64_t items) : ctx(c), stream(s), on(c->profiling) {
         if (!on) return;
         sp.family = family;
         sp.items = items;
@@ -363,11 +405,11 @@ struct ProfScope {
             if (!ctx->event_pool.empty()) { *e = ctx->event_pool.back(); ctx->event_pool.pop_back(); }
             else (void)hipEventCreate(e);
         }
-        (void)hipEventRecord(sp.a, ctx->stream);
+        (void)hipEventRecord(sp.a, stream);
     }
     ~ProfScope() {
         if (!on) return;
-        (void)hipEventRecord(sp.b, ctx->stream);
+        (void)hipEventRecord(sp.b, stream);
         ctx->spans.push_back(sp);
     }
 };
@@ -387,20 +429,17 @@ static void prof_drain(PtrContext *ctx) {
 }
 
 static inline unsigned nblocks(int n) { return (unsigned)((n + TPB - 1) / TPB); }
+static inline unsigned clampu(unsigned v, unsigned lo, unsigned hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-#define FETCH_SLOTS 256
-/* one launch of the persistent tracer over io.n rays */
-static int launch_ptrace(PtrContext *ctx, TraceIO io, bool any, bool count, int family) {
-    if (io.n <= 0) return PTR_OK;
-    io.counter = ctx->fetch + (ctx->fetch_next++ % FETCH_SLOTS);
-    HIPCHK(hipMemsetAsync(io.counter, 0, sizeof(int), ctx->stream));
-    unsigned blocks = nblocks(io.n);
-    if (blocks > (unsigned)ctx->persist_blocks) blocks = (unsigned)ctx->persist_blocks;
-    ProfScope ps(ctx, family, (uint64_t)io.n);
-    if (any) hipLaunchKernelGGL((k_ptrace<true, false>), dim3(blocks), dim3(TRACE_TPB), 0, ctx->stream, ctx->sc, io, ctx->ctrs);
-    else if (count) hipLaunchKernelGGL((k_ptrace<false, true>), dim3(blocks), dim3(TRACE_TPB), 0, ctx->stream, ctx->sc, io, ctx->ctrs);
-    else hipLaunchKernelGGL((k_ptrace<false, false>), dim3(blocks), dim3(TRACE_TPB), 0, ctx->stream, ctx->sc, io, ctx->ctrs);
-    return PTR_OK;
+#define API_FETCH_SLOTS 256
+/* one launch of the persistent tracer; n_upper bounds the ray count for sizing the grid (the
+ * count itself may be in device memory, io.n_ptr); io.counter must be zero when the kernel starts */
+static void launch_ptrace(PtrContext *ctx, hipStream_t s, const TraceIO &io, int n_upper, bool any, bool count, int family) {
+    unsigned blocks = clampu(nblocks(n_upper), 1, (unsigned)ctx->persist_blocks);
+    ProfScope ps(ctx, s, family, (uint64_t)(io.n_ptr ? 0 : io.n));
+    if (any) hipLaunchKernelGGL((k_ptrace<true, false>), dim3(blocks), dim3(TRACE_TPB), 0, s, ctx->sc, io, ctx->ctrs);
+    else if (count) hipLaunchKernelGGL((k_ptrace<false, true>), dim3(blocks), dim3(TRACE_TPB), 0, s, ctx->sc, io, ctx->ctrs);
+    else hipLaunchKernelGGL((k_ptrace<false, false>), dim3(blocks), dim3(TRACE_TPB), 0, s, ctx->sc, io, ctx->ctrs);
 }
 static TraceIO soa_io(int n, const int *queue, long long plane, const float *o, const float *d, const float *tmax, int *prim, int *face,
                       float *t, float *b0, float *b1) {
@@ -415,9 +454,149 @@ static TraceIO soa_io(int n, const int *queue, long long plane, const float *o, 
     io.prim_es = io.face_es = io.t_es = io.b0_es = io.b1_es = 4;
     return io;
 }
+static int api_trace(PtrContext *ctx, TraceIO io, bool any) {
+    io.counter = ctx->api_fetch + (ctx->api_fetch_next++ % API_FETCH_SLOTS);
+    HIPCHK(hipMemsetAsync(io.counter, 0, sizeof(int), ctx->stream));
+    launch_ptrace(ctx, ctx->stream, io, io.n, any, !any && ctx->count_traversal, K_API_TRACE);
+    HIPCHK(hipGetLastError());
+    return PTR_OK;
+}
+
+/* One bounce of a pass on a lane: trace the live paths, shade them, trace and sum their
+ * direct-light records.  n_ptr / n_host: number of live paths (device counter of the previous
+ * bounce, or a host value); n_upper: an upper bound used only to size grids; cslot: which
+ * [4]+[3] counter block of the lane this bounce writes (must be zero). */
+static void enqueue_bounce(PtrContext *ctx, Lane &l, const PassParams &prm, const int *n_ptr, int n_host, int n_upper, const int *q_cur,
+                           int *q_next, int cslot) {
+    hipStream_t s = l.stream;
+    int *q_nee = l.queues[2], *q_shadow = l.queues[3], *q_mis = l.queues[4];
+    int *cnt = l.counts + 4 * cslot;
+    int *fetch = l.counts + 4 * MAX_ITERS + 3 * cslot;
+    const unsigned stride_blocks = clampu(nblocks(n_upper), 32, 2048);
+    {
+        TraceIO io = soa_io(n_host, q_cur, l.pipe.cap, l.pipe.ro, l.pipe.rd, nullptr, l.pipe.hprim, l.pipe.hface, l.pipe.ht, nullptr, nullptr);
+        io.n_ptr = n_ptr;
+        io.counter = fetch + 0;
+        launch_ptrace(ctx, s, io, n_upper, false, ctx->count_traversal, K_TRACE);
+    }
+    {
+        ProfScope ps(ctx, s, K_SHADE, (uint64_t)(n_ptr ? 0 : n_host));
+        hipLaunchKernelGGL(k_shade, dim3(stride_blocks), dim3(TPB), 0, s, ctx->sc, l.pipe, prm, n_ptr, n_host, q_cur, q_next, q_nee, q_shadow, q_mis,
+                           cnt, ctx->ctrs);
+    }
+    /* the walks of VisibilityTester::Tr / IntersectTr can only go past their first hit under
+     * Li_VolPath and only if some primitive has no material (medium boundary, emitter) */
+    const bool walk = prm.integrator == PTR_LI_VOLPATH && !ctx->scene_all_opaque;
+    if (walk) {
+        {
+            ProfScope ps(ctx, s, K_SHADOW, 0);
+            hipLaunchKernelGGL(k_shadow_walk, dim3(stride_blocks), dim3(TPB), 0, s, ctx->sc, l.pipe, (const int *)(cnt + 2), 0, (const int *)q_shadow, ctx->ctrs);
+        }
+        {
+            ProfScope ps(ctx, s, K_MIS, 0);
+            hipLaunchKernelGGL(k_mis_walk, dim3(stride_blocks), dim3(TPB), 0, s, ctx->sc, l.pipe, (const int *)(cnt + 1), 0, (const int *)q_nee, ctx->ctrs);
+        }
+    } else {
+        NeeRec *nee = l.pipe.nee;
+        { /* shadow rays: any hit within (0, 1 - ShadowEpsilon) */
+            TraceIO io;
+            memset(&io, 0, sizeof(io));
+            io.queue = q_shadow; io.n_ptr = cnt + 2;
+            io.o = (const char *)nee + offsetof(NeeRec, oA); io.o_es = sizeof(NeeRec); io.o_cs = 4;
+            io.d = (const char *)nee + offsetof(NeeRec, dA); io.d_es = sizeof(NeeRec); io.d_cs = 4;
+            io.tmax_const = 1 - 0.0001f;
+            io.prim = (char *)nee + offsetof(NeeRec, occA); io.prim_es = sizeof(NeeRec);
+            io.counter = fetch + 1;
+            launch_ptrace(ctx, s, io, n_upper, true, false, K_SHADOW);
+        }
+        { /* MIS rays: closest hit */
+            TraceIO io;
+            memset(&io, 0, sizeof(io));
+            io.queue = q_mis; io.n_ptr = cnt + 3;
+            io.o = (const char *)nee + offsetof(NeeRec, oB); io.o_es = sizeof(NeeRec); io.o_cs = 4;
+            io.d = (const char *)nee + offsetof(NeeRec, dB); io.d_es = sizeof(NeeRec); io.d_cs = 4;
+            io.tmax_const = FLT_MAX;
+            io.prim = (char *)nee + offsetof(NeeRec, hitB); io.prim_es = sizeof(NeeRec);
+            io.t = (char *)nee + offsetof(NeeRec, tB); io.t_es = sizeof(NeeRec);
+            io.counter = fetch + 2;
+            launch_ptrace(ctx, s, io, n_upper, false, false, K_MIS);
+        }
+        {
+            ProfScope ps(ctx, s, K_RESOLVE, 0);
+            hipLaunchKernelGGL(k_nee_resolve, dim3(stride_blocks), dim3(TPB), 0, s, ctx->sc, l.pipe, (const int *)(cnt + 1), 0, (const int *)q_nee, ctx->ctrs);
+        }
+    }
+}
+
+/* one pass on a lane: nb samples (first, first+step, ...) of every pixel */
+static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int step, int nb, int integrator) {
+    PassParams prm;
+    prm.seed = ctx->seed;
+    prm.npix = ctx->npix;
+    prm.width = ctx->width;
+    prm.height = ctx->height;
+    prm.sample_first = first;
+    prm.sample_step = step;
+    prm.integrator = integrator;
+    hipStream_t s = l.stream;
+    const int slots = ctx->npix * nb;
+    const size_t cbytes = (size_t)(7 * MAX_ITERS) * sizeof(int);
+    HIPCHK(hipMemsetAsync(l.counts, 0, cbytes, s));
+    {
+        ProfScope ps(ctx, s, K_RAYGEN, (uint64_t)slots);
+        hipLaunchKernelGGL(k_raygen, dim3(nblocks(slots)), dim3(TPB), 0, s, ctx->sc, ctx->cam, l.pipe, prm, slots);
+    }
+    ctx->camera_rays += (uint64_t)slots;
+
+    /* Bounces a path can take: Li_Direct 1; Li_Path bounces 0..9; Li_PathSampled 0..10 and
+     * Li_VolPath 0..15 (the vertex at max_bounces still adds emission, main.cpp:183,289).  Crossing
+     * a medium boundary without material does not count as a bounce (main.cpp:187-191), so scenes
+     * with such primitives have no bound and take the synchronous loop below. */
+    const int fixed_iters = integrator == PTR_LI_DIRECT ? 1 : integrator == PTR_LI_PATH ? 10 : integrator == PTR_LI_PATHSAMPLED ? 11 : 16;
+    const int *q_cur = nullptr; /* identity */
+    int qi = 0;
+    if (!ctx->scene_passthrough) {
+        /* no host round trip: every launch reads its count from the counter block the previous
+         * bounce wrote; grids are sized from an estimate and stride over whatever is there */
+        for (int k = 0; k < fixed_iters; k++) {
+            int *q_next = l.queues[qi];
+            int upper = slots >> (k < 6 ? k : 6);
+            if (upper < 1) upper = 1;
+            enqueue_bounce(ctx, l, prm, k == 0 ? nullptr : l.counts + 4 * (k - 1), slots, k == 0 ? slots : upper, q_cur, q_next, k);
+            q_cur = q_next;
+            qi ^= 1;
+        }
+    } else {
+        int n_cur = slots;
+        for (int iter = 0; n_cur > 0 && iter < 65536; iter++) {
+            int *q_next = l.queues[qi];
+            const int cslot = iter % MAX_ITERS;
+            if (iter >= MAX_ITERS) HIPCHK(hipMemsetAsync(l.counts + 4 * cslot, 0, 4 * sizeof(int), s));
+            if (iter >= MAX_ITERS) HIPCHK(hipMemsetAsync(l.counts + 4 * MAX_ITERS + 3 * cslot, 0, 3 * sizeof(int), s));
+            enqueue_bounce(ctx, l, prm, nullptr, n_cur, n_cur, q_cur, q_next, cslot);
+            HIPCHK(hipMemcpyAsync(l.counts_host, l.counts + 4 * cslot, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            n_cur = l.counts_host[0];
+            q_cur = q_next;
+            qi ^= 1;
+        }
+    }
+    /* the film is accumulated in sample order: this pass's film kernel follows the previous one's */
+    if (ctx->last_film_lane >= 0 && ctx->last_film_lane != lane_index)
+        HIPCHK(hipStreamWaitEvent(s, ctx->lanes[ctx->last_film_lane].film_done, 0));
+    {
+        ProfScope ps(ctx, s, K_FILM, (uint64_t)ctx->npix);
+        hipLaunchKernelGGL(k_film, dim3(nblocks(ctx->npix)), dim3(TPB), 0, s, l.pipe, ctx->npix, nb, ctx->we, ctx->acc, ctx->samples);
+    }
+    HIPCHK(hipEventRecord(l.film_done, s));
+    ctx->last_film_lane = lane_index;
+    HIPCHK(hipGetLastError());
+    return PTR_OK;
+}
 
 extern "C" {
 
+int ptr_destroy(PtrContext *ctx);
 const char *ptr_last_error(void) { return g_err.c_str(); }
 
 int ptr_create(int device, PtrContext **out) {
@@ -436,19 +615,21 @@ int ptr_create(int device, PtrContext **out) {
     ctx->device = device;
     memset(&ctx->sc, 0, sizeof(ctx->sc));
     memset(&ctx->cam, 0, sizeof(ctx->cam));
-    memset(&ctx->pipe, 0, sizeof(ctx->pipe));
     memset(ctx->prof_ms, 0, sizeof(ctx->prof_ms));
     memset(ctx->prof_launches, 0, sizeof(ctx->prof_launches));
     memset(ctx->prof_items, 0, sizeof(ctx->prof_items));
-    if (hipMalloc((void **)&ctx->ctrs, C_COUNT * sizeof(unsigned long long)) != hipSuccess) {
-        delete ctx;
-        return set_err(PTR_ERR_HIP, "hipMalloc(counters) failed");
+    bool ok = hipMalloc((void **)&ctx->ctrs, C_COUNT * sizeof(unsigned long long)) == hipSuccess &&
+              hipMemset(ctx->ctrs, 0, C_COUNT * sizeof(unsigned long long)) == hipSuccess &&
+              hipMalloc((void **)&ctx->api_fetch, API_FETCH_SLOTS * sizeof(int)) == hipSuccess;
+    for (Lane &l : ctx->lanes) {
+        memset(&l.pipe, 0, sizeof(l.pipe));
+        ok = ok && hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&l.film_done, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&l.joined, hipEventDisableTiming) == hipSuccess;
     }
-    (void)hipMemset(ctx->ctrs, 0, C_COUNT * sizeof(unsigned long long));
-    if (hipMalloc((void **)&ctx->fetch, FETCH_SLOTS * sizeof(int)) != hipSuccess) {
-        (void)hipFree(ctx->ctrs);
-        delete ctx;
-        return set_err(PTR_ERR_HIP, "hipMalloc(fetch cursors) failed");
+    if (!ok) {
+        ptr_destroy(ctx);
+        return set_err(PTR_ERR_HIP, "context setup failed (hipMalloc / stream / event)");
     }
     /* persistent grid: enough 256-thread blocks to fill every CU at the tracer's occupancy */
     ctx->persist_blocks = prop.multiProcessorCount * 4;
@@ -459,13 +640,18 @@ int ptr_create(int device, PtrContext **out) {
 int ptr_destroy(PtrContext *ctx) {
     if (!ctx) return PTR_OK;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)sync_all(ctx);
     prof_drain(ctx);
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     free_scene(ctx);
     free_film(ctx);
+    for (Lane &l : ctx->lanes) {
+        if (l.film_done) (void)hipEventDestroy(l.film_done);
+        if (l.joined) (void)hipEventDestroy(l.joined);
+        if (l.stream) (void)hipStreamDestroy(l.stream);
+    }
     if (ctx->ctrs) (void)hipFree(ctx->ctrs);
-    if (ctx->fetch) (void)hipFree(ctx->fetch);
+    if (ctx->api_fetch) (void)hipFree(ctx->api_fetch);
     delete ctx;
     return PTR_OK;
 }
@@ -483,7 +669,7 @@ int ptr_scene_upload(PtrContext *ctx, const PtrFlatScene *scene) {
     std::string err;
     rc = ptr_flatten(scene, &hs, &err);
     if (rc) return set_err(rc, err);
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if ((rc = sync_all(ctx))) return rc;
     free_scene(ctx);
     DScene sc;
     memset(&sc, 0, sizeof(sc));
@@ -541,8 +727,11 @@ int ptr_scene_upload(PtrContext *ctx, const PtrFlatScene *scene) {
     ctx->bvh_bytes = (int64_t)(hs.nodes.size() * sizeof(Node64) + hs.items.size() * sizeof(Item48));
     ctx->scene_has_media = hs.has_media;
     ctx->scene_all_opaque = true;
-    for (const DPrim &pr : hs.prims)
+    ctx->scene_passthrough = false;
+    for (const DPrim &pr : hs.prims) {
         if (pr.material < 0) ctx->scene_all_opaque = false;
+        if (pr.material < 0 && !(pr.flags & PF_EMISSIVE)) ctx->scene_passthrough = true;
+    }
     ctx->has_scene = true;
     return PTR_OK;
 }
@@ -567,7 +756,7 @@ int ptr_film_init(PtrContext *ctx, int width, int height, uint64_t seed) {
     int rc = ctx_use(ctx);
     if (rc) return rc;
     if (width <= 0 || height <= 0 || (int64_t)width * height > (1 << 28)) return set_err(PTR_ERR_INVALID, "bad film size");
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if ((rc = sync_all(ctx))) return rc;
     int npix = width * height;
     if (!ctx->has_film || npix != ctx->npix) {
         free_film(ctx);
@@ -580,26 +769,30 @@ int ptr_film_init(PtrContext *ctx, int width, int height, uint64_t seed) {
         HIPCHK(hipMalloc((void **)&ctx->we, 3 * sizeof(float) * npix));
         HIPCHK(hipMalloc((void **)&ctx->acc, sizeof(double) * npix));
         HIPCHK(hipMalloc((void **)&ctx->samples, sizeof(long long) * npix));
-        HIPCHK(hipMalloc((void **)&ctx->pipe.ro, 3 * sizeof(float) * cap));
-        HIPCHK(hipMalloc((void **)&ctx->pipe.rd, 3 * sizeof(float) * cap));
-        HIPCHK(hipMalloc((void **)&ctx->pipe.hprim, sizeof(int) * cap));
-        HIPCHK(hipMalloc((void **)&ctx->pipe.hface, sizeof(int) * cap));
-        HIPCHK(hipMalloc((void **)&ctx->pipe.ht, sizeof(float) * cap));
-        HIPCHK(hipMalloc((void **)&ctx->pipe.paths, sizeof(PathRec) * cap));
-        HIPCHK(hipMalloc((void **)&ctx->pipe.nee, sizeof(NeeRec) * cap));
-        for (int q = 0; q < 5; q++) HIPCHK(hipMalloc((void **)&ctx->queues[q], sizeof(int) * cap));
-        HIPCHK(hipMalloc((void **)&ctx->counts, 4 * sizeof(int)));
-        HIPCHK(hipHostMalloc((void **)&ctx->counts_host, 4 * sizeof(int), hipHostMallocDefault));
-        ctx->pipe.cap = (int)cap;
+        for (Lane &l : ctx->lanes) {
+            HIPCHK(hipMalloc((void **)&l.pipe.ro, 3 * sizeof(float) * cap));
+            HIPCHK(hipMalloc((void **)&l.pipe.rd, 3 * sizeof(float) * cap));
+            HIPCHK(hipMalloc((void **)&l.pipe.hprim, sizeof(int) * cap));
+            HIPCHK(hipMalloc((void **)&l.pipe.hface, sizeof(int) * cap));
+            HIPCHK(hipMalloc((void **)&l.pipe.ht, sizeof(float) * cap));
+            HIPCHK(hipMalloc((void **)&l.pipe.paths, sizeof(PathRec) * cap));
+            HIPCHK(hipMalloc((void **)&l.pipe.nee, sizeof(NeeRec) * cap));
+            for (int q = 0; q < 5; q++) HIPCHK(hipMalloc((void **)&l.queues[q], sizeof(int) * cap));
+            HIPCHK(hipMalloc((void **)&l.counts, 7 * MAX_ITERS * sizeof(int)));
+            HIPCHK(hipHostMalloc((void **)&l.counts_host, 4 * sizeof(int), hipHostMallocDefault));
+            l.pipe.cap = (int)cap;
+        }
     }
     ctx->width = width;
     ctx->height = height;
     ctx->npix = npix;
     ctx->seed = seed;
     ctx->sample_cursor = 0;
-    HIPCHK(hipMemsetAsync(ctx->we, 0, 3 * sizeof(float) * npix, ctx->stream));
-    HIPCHK(hipMemsetAsync(ctx->acc, 0, sizeof(double) * npix, ctx->stream));
-    HIPCHK(hipMemsetAsync(ctx->samples, 0, sizeof(long long) * npix, ctx->stream));
+    ctx->last_film_lane = -1;
+    HIPCHK(hipMemset(ctx->we, 0, 3 * sizeof(float) * npix));
+    HIPCHK(hipMemset(ctx->acc, 0, sizeof(double) * npix));
+    HIPCHK(hipMemset(ctx->samples, 0, sizeof(long long) * npix));
+    HIPCHK(hipDeviceSynchronize());
     ctx->has_film = true;
     return PTR_OK;
 }
@@ -609,98 +802,6 @@ int ptr_film_shard(PtrContext *ctx, int sample_offset, int sample_stride) {
     if (sample_stride < 1 || sample_offset < 0 || sample_offset >= sample_stride) return set_err(PTR_ERR_INVALID, "bad shard (offset, stride)");
     ctx->shard_offset = sample_offset;
     ctx->shard_stride = sample_stride;
-    return PTR_OK;
-}
-
-/* one pass: nb samples (first, first+step, ...) of every pixel */
-static int run_pass(PtrContext *ctx, int first, int step, int nb, int integrator) {
-    PassParams prm;
-    prm.seed = ctx->seed;
-    prm.npix = ctx->npix;
-    prm.width = ctx->width;
-    prm.height = ctx->height;
-    prm.sample_first = first;
-    prm.sample_step = step;
-    prm.integrator = integrator;
-    hipStream_t s = ctx->stream;
-    const int slots = ctx->npix * nb;
-    {
-        ProfScope ps(ctx, K_RAYGEN, (uint64_t)slots);
-        hipLaunchKernelGGL(k_raygen, dim3(nblocks(slots)), dim3(TPB), 0, s, ctx->sc, ctx->cam, ctx->pipe, prm, slots);
-    }
-    ctx->camera_rays += (uint64_t)slots;
-    int n_cur = slots;
-    const int *q_cur = nullptr; /* identity */
-    int qi = 0;
-    for (int iter = 0; n_cur > 0 && iter < 4096; iter++) {
-        int *q_next = ctx->queues[qi];
-        int *q_nee = ctx->queues[2], *q_shadow = ctx->queues[3], *q_mis = ctx->queues[4];
-        HIPCHK(hipMemsetAsync(ctx->counts, 0, 4 * sizeof(int), s));
-        {
-            TraceIO io = soa_io(n_cur, q_cur, ctx->pipe.cap, ctx->pipe.ro, ctx->pipe.rd, nullptr, ctx->pipe.hprim, ctx->pipe.hface,
-                                ctx->pipe.ht, nullptr, nullptr);
-            int rc = launch_ptrace(ctx, io, false, ctx->count_traversal, K_TRACE);
-            if (rc) return rc;
-        }
-        {
-            ProfScope ps(ctx, K_SHADE, (uint64_t)n_cur);
-            hipLaunchKernelGGL(k_shade, dim3(nblocks(n_cur)), dim3(TPB), 0, s, ctx->sc, ctx->pipe, prm, n_cur, q_cur, q_next, q_nee, q_shadow,
-                               q_mis, ctx->counts, ctx->ctrs);
-        }
-        HIPCHK(hipMemcpyAsync(ctx->counts_host, ctx->counts, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-        int n_next = ctx->counts_host[0], n_nee = ctx->counts_host[1], n_shadow = ctx->counts_host[2], n_mis = ctx->counts_host[3];
-        /* the walks of VisibilityTester::Tr / IntersectTr can only go past their first hit under
-         * Li_VolPath and only if some primitive has no material (medium boundary, emitter) */
-        const bool loop = integrator == PTR_LI_VOLPATH && !ctx->scene_all_opaque;
-        if (loop) {
-            if (n_shadow > 0) {
-                ProfScope ps(ctx, K_SHADOW, (uint64_t)n_shadow);
-                hipLaunchKernelGGL(k_shadow<true>, dim3(nblocks(n_shadow)), dim3(TPB), 0, s, ctx->sc, ctx->pipe, n_shadow, (const int *)q_shadow, ctx->ctrs);
-            }
-            if (n_nee > 0) {
-                ProfScope ps(ctx, K_MIS, (uint64_t)n_nee);
-                hipLaunchKernelGGL(k_mis<true>, dim3(nblocks(n_nee)), dim3(TPB), 0, s, ctx->sc, ctx->pipe, n_nee, (const int *)q_nee, ctx->ctrs);
-            }
-        } else {
-            NeeRec *nee = ctx->pipe.nee;
-            if (n_shadow > 0) { /* shadow rays: any hit within (0, 1 - ShadowEpsilon) */
-                TraceIO io;
-                memset(&io, 0, sizeof(io));
-                io.queue = q_shadow; io.n = n_shadow;
-                io.o = (const char *)nee + offsetof(NeeRec, oA); io.o_es = sizeof(NeeRec); io.o_cs = 4;
-                io.d = (const char *)nee + offsetof(NeeRec, dA); io.d_es = sizeof(NeeRec); io.d_cs = 4;
-                io.tmax_const = 1 - 0.0001f;
-                io.prim = (char *)nee + offsetof(NeeRec, occA); io.prim_es = sizeof(NeeRec);
-                int rc = launch_ptrace(ctx, io, true, false, K_SHADOW);
-                if (rc) return rc;
-            }
-            if (n_mis > 0) { /* MIS rays: closest hit */
-                TraceIO io;
-                memset(&io, 0, sizeof(io));
-                io.queue = q_mis; io.n = n_mis;
-                io.o = (const char *)nee + offsetof(NeeRec, oB); io.o_es = sizeof(NeeRec); io.o_cs = 4;
-                io.d = (const char *)nee + offsetof(NeeRec, dB); io.d_es = sizeof(NeeRec); io.d_cs = 4;
-                io.tmax_const = FLT_MAX;
-                io.prim = (char *)nee + offsetof(NeeRec, hitB); io.prim_es = sizeof(NeeRec);
-                io.t = (char *)nee + offsetof(NeeRec, tB); io.t_es = sizeof(NeeRec);
-                int rc = launch_ptrace(ctx, io, false, false, K_MIS);
-                if (rc) return rc;
-            }
-            if (n_nee > 0) {
-                ProfScope ps(ctx, K_RESOLVE, (uint64_t)n_nee);
-                hipLaunchKernelGGL(k_nee_resolve, dim3(nblocks(n_nee)), dim3(TPB), 0, s, ctx->sc, ctx->pipe, n_nee, (const int *)q_nee, ctx->ctrs);
-            }
-        }
-        q_cur = q_next;
-        n_cur = n_next;
-        qi ^= 1;
-    }
-    {
-        ProfScope ps(ctx, K_FILM, (uint64_t)ctx->npix);
-        hipLaunchKernelGGL(k_film, dim3(nblocks(ctx->npix)), dim3(TPB), 0, s, ctx->pipe, ctx->npix, nb, ctx->we, ctx->acc, ctx->samples);
-    }
-    HIPCHK(hipGetLastError());
     return PTR_OK;
 }
 
@@ -716,20 +817,32 @@ int ptr_render(PtrContext *ctx, int ns, int integrator) {
     /* first sample index >= begin owned by this shard */
     int stride = ctx->shard_stride;
     int first = begin + ((ctx->shard_offset - begin) % stride + stride) % stride;
+    bool used[N_LANES] = {false, false, false, false};
     while (first < end) {
         int remaining = (end - first + stride - 1) / stride;
-        int nb = remaining < ctx->nb_max ? remaining : ctx->nb_max;
-        rc = run_pass(ctx, first, stride, nb, integrator);
+        /* spread the samples of this call over the lanes before filling a lane's batch */
+        int nb = (remaining + N_LANES - 1) / N_LANES;
+        if (nb > ctx->nb_max) nb = ctx->nb_max;
+        if (nb < 1) nb = 1;
+        int li = ctx->next_lane++ % N_LANES;
+        rc = run_pass(ctx, ctx->lanes[li], li, first, stride, nb, integrator);
         if (rc) return rc;
+        used[li] = true;
         first += nb * stride;
     }
+    /* work queued on the caller's stream after this call sees the finished film */
+    for (int li = 0; li < N_LANES; li++)
+        if (used[li]) {
+            HIPCHK(hipEventRecord(ctx->lanes[li].joined, ctx->lanes[li].stream));
+            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->lanes[li].joined, 0));
+        }
     return PTR_OK;
 }
 
 int ptr_sync(PtrContext *ctx) {
     int rc = ctx_use(ctx);
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if ((rc = sync_all(ctx))) return rc;
     HIPCHK(hipGetLastError());
     return PTR_OK;
 }
@@ -738,7 +851,7 @@ int ptr_film_read(PtrContext *ctx, float *we_rgb, double *acc_weight, int64_t *s
     int rc = ctx_use(ctx);
     if (rc) return rc;
     if (!ctx->has_film) return set_err(PTR_ERR_STATE, "no film");
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if ((rc = sync_all(ctx))) return rc;
     if (we_rgb) HIPCHK(hipMemcpy(we_rgb, ctx->we, 3 * sizeof(float) * ctx->npix, hipMemcpyDeviceToHost));
     if (acc_weight) HIPCHK(hipMemcpy(acc_weight, ctx->acc, sizeof(double) * ctx->npix, hipMemcpyDeviceToHost));
     if (samples) HIPCHK(hipMemcpy(samples, ctx->samples, sizeof(int64_t) * ctx->npix, hipMemcpyDeviceToHost));
@@ -759,7 +872,7 @@ int ptr_counters_read(PtrContext *ctx, PtrCounters *out) {
     if (rc) return rc;
     if (!out) return set_err(PTR_ERR_INVALID, "null out pointer");
     static_assert(sizeof(PtrCounters) == C_COUNT * sizeof(uint64_t), "counter layout");
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if ((rc = sync_all(ctx))) return rc;
     HIPCHK(hipMemcpy(out, ctx->ctrs, sizeof(PtrCounters), hipMemcpyDeviceToHost));
     out->camera_rays = ctx->camera_rays;
     return PTR_OK;
@@ -768,8 +881,9 @@ int ptr_counters_read(PtrContext *ctx, PtrCounters *out) {
 int ptr_counters_reset(PtrContext *ctx) {
     int rc = ctx_use(ctx);
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if ((rc = sync_all(ctx))) return rc;
     HIPCHK(hipMemset(ctx->ctrs, 0, C_COUNT * sizeof(unsigned long long)));
+    HIPCHK(hipDeviceSynchronize());
     ctx->camera_rays = 0;
     return PTR_OK;
 }
@@ -785,7 +899,7 @@ int ptr_generate_rays(PtrContext *ctx, int sample, float *d_o, float *d_d, float
     prm.npix = ctx->npix;
     prm.width = ctx->width;
     prm.height = ctx->height;
-    ProfScope ps(ctx, K_RAYGEN, (uint64_t)ctx->npix);
+    ProfScope ps(ctx, ctx->stream, K_RAYGEN, (uint64_t)ctx->npix);
     hipLaunchKernelGGL(k_raygen_only, dim3(nblocks(ctx->npix)), dim3(TPB), 0, ctx->stream, ctx->cam, prm, sample, d_o, d_d, d_weight);
     HIPCHK(hipGetLastError());
     return PTR_OK;
@@ -798,13 +912,7 @@ int ptr_trace_closest(PtrContext *ctx, int n, const float *d_o, const float *d_d
     if (!ctx->has_scene) return set_err(PTR_ERR_STATE, "no scene uploaded");
     if (n < 0 || (n > 0 && (!d_o || !d_d || !d_prim || !d_face || !d_t))) return set_err(PTR_ERR_INVALID, "bad ray batch");
     if (n == 0) return PTR_OK;
-    {
-        TraceIO io = soa_io(n, nullptr, n, d_o, d_d, d_tmax, d_prim, d_face, d_t, d_b0, d_b1);
-        int rc2 = launch_ptrace(ctx, io, false, ctx->count_traversal, K_API_TRACE);
-        if (rc2) return rc2;
-    }
-    HIPCHK(hipGetLastError());
-    return PTR_OK;
+    return api_trace(ctx, soa_io(n, nullptr, n, d_o, d_d, d_tmax, d_prim, d_face, d_t, d_b0, d_b1), false);
 }
 
 int ptr_trace_occluded(PtrContext *ctx, int n, const float *d_o, const float *d_d, const float *d_tmax, int32_t *d_occluded) {
@@ -813,13 +921,7 @@ int ptr_trace_occluded(PtrContext *ctx, int n, const float *d_o, const float *d_
     if (!ctx->has_scene) return set_err(PTR_ERR_STATE, "no scene uploaded");
     if (n < 0 || (n > 0 && (!d_o || !d_d || !d_occluded))) return set_err(PTR_ERR_INVALID, "bad ray batch");
     if (n == 0) return PTR_OK;
-    {
-        TraceIO io = soa_io(n, nullptr, n, d_o, d_d, d_tmax, d_occluded, nullptr, nullptr, nullptr, nullptr);
-        int rc2 = launch_ptrace(ctx, io, true, false, K_API_TRACE);
-        if (rc2) return rc2;
-    }
-    HIPCHK(hipGetLastError());
-    return PTR_OK;
+    return api_trace(ctx, soa_io(n, nullptr, n, d_o, d_d, d_tmax, d_occluded, nullptr, nullptr, nullptr, nullptr), true);
 }
 
 /* on: bit 0 = time every launch with HIP events, bit 1 = count child boxes / leaf items tested */
