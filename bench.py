@@ -4,7 +4,7 @@
 Workload at N=1 (BASELINE.json configs[1]): 871,200-triangle torus-knot mesh ("dragon-class"
 stand-in, the author's assets are not available), rough-glass microfacet material, light-map
 sky, 1920x1080, Li_VolPath (the reference's default integrator, main.cpp:447).  One *step* is one
-1-spp pass of the whole image through the wavefront pipeline (raygen -> {trace, shade, nee} per
+batch of --spp (8) samples of every pixel - 1/32 of the 256 spp of configs[1] - through the wavefront pipeline (raygen -> {trace, shade, nee} per
 bounce -> film); scene, BVH and film are resident in HBM before the timed region starts.
 
 value = (closest-hit + any-hit scene queries of all ranks) / wall time, in Mrays/s.
@@ -55,8 +55,9 @@ def cpu_baseline(scene, width, height, integrator, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp", type=int, default=8, help="samples per pixel per step and per GPU (one batch)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--segments", type=int, default=660, help="knot tessellation: 2*s*s triangles (660 -> 871,200)")
@@ -101,8 +102,8 @@ def main():
         torch.cuda.synchronize()
 
     def step():
-        # one 1-spp pass on every rank: `world` consecutive sample indices, one per rank
-        r.render(world, args.integrator)
+        # one batch on every rank: args.spp samples of every pixel (rank r takes the sample indices = r mod world)
+        r.render(world * args.spp, args.integrator)
 
     for _ in range(args.warmup):
         step()
@@ -168,9 +169,9 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "configs[1]: %d-triangle torus-knot mesh (dragon-class stand-in), %s, light-map sky, %dx%d, "
-                                   "1 spp per step per GPU, integrator %d (Li_VolPath=3)" %
+                                   "%d spp per step per GPU, integrator %d (Li_VolPath=3)" %
                                    (2 * args.segments * args.segments, ["rough glass (microfacet)", "plastic", "specular glass", "matte"][args.variant],
-                                    W, H, args.integrator),
+                                    W, H, args.spp, args.integrator),
                        "triangles": 2 * args.segments * args.segments, "width": W, "height": H,
                        "bvh_nodes": bvh["nodes"], "bvh_items": bvh["items"], "bvh_bytes": bvh["bytes"],
                        "scene_upload_s": round(t_up, 3), "parallelism": "samples round-robin over %d GPU(s), scene replicated" % world},

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
-HIP_LIB = os.path.join(LIB_DIR, "libptr_hip.so")
+HIP_LIB = os.environ.get("PTR_HIP_LIB") or os.path.join(LIB_DIR, "libptr_hip.so")  # override: kernel-variant experiments
 HOST_LIB = os.path.join(LIB_DIR, "libpt_host.so")
 
 PTR_OK, PTR_ERR_INVALID, PTR_ERR_HIP, PTR_ERR_STATE, PTR_ERR_LIMIT = 0, 1, 2, 3, 4

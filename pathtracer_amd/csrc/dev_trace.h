@@ -42,7 +42,13 @@ enum { TM_IDLE = 0, TM_TOP = 1, TM_TOPLEAF = 2, TM_GEOM = 3 };
 #define PT_POP() (--sp, sp < LDS_STACK ? lds[sp * TRACE_TPB] : ovf[(sp < BVH_STACK ? sp : BVH_STACK - 1) - LDS_STACK])
 
 /* inner loops hand control back (to let finished lanes refill) once this few lanes remain in them */
+#ifndef PT_MIN_ACTIVE
 #define PT_MIN_ACTIVE 20
+#endif
+/* idle lanes wait until this many can be refilled together */
+#ifndef PT_REFILL
+#define PT_REFILL 24
+#endif
 
 template <bool ANY, bool COUNT>
 PD void persistent_trace(const DScene &sc, const TraceIO &io, int *lds, unsigned *total_nodes, unsigned *total_items) {
@@ -88,7 +94,9 @@ PD void persistent_trace(const DScene &sc, const TraceIO &io, int *lds, unsigned
     for (;;) {
         /* ---- refill idle lanes ---- */
         unsigned long long idle = __ballot(mode == TM_IDLE);
-        if (idle) {
+        /* refill in batches: the top-level phase a new ray starts with (analytic primitives: a
+         * sphere costs a double-precision quadratic) should run with many lanes, not one or two */
+        if (idle && (__popcll(idle) >= PT_REFILL || __ballot(mode == TM_GEOM) == 0)) {
             if (pool_pos >= pool_end && !exhausted) {
                 int base = 0;
                 if (lane == 0) base = atomicAdd(io.counter, 64);

@@ -16,6 +16,7 @@
 #include <cfloat>
 #include <cstddef>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -24,6 +25,9 @@
  * device helpers
  * ---------------------------------------------------------------------------------------- */
 #define TPB 256
+#ifndef PT_WAVES
+#define PT_WAVES 5 /* wavefronts per SIMD the persistent tracer is compiled for */
+#endif
 
 struct Pipe {
     float *ro, *rd;      /* 3 planes of cap floats each */
@@ -132,7 +136,7 @@ __global__ void __launch_bounds__(TPB) k_raygen_only(DCamera cam, PassParams prm
 /* Aggregator::Intersect (ANY = false) / VisibilityTester::Unoccluded (ANY = true) over a queue of
  * rays: persistent wavefronts, see dev_trace.h */
 template <bool ANY, bool COUNT>
-__global__ void __launch_bounds__(TRACE_TPB) k_ptrace(DScene sc, TraceIO io, unsigned long long *ctrs) {
+__global__ void __launch_bounds__(TRACE_TPB) __attribute__((amdgpu_waves_per_eu(PT_WAVES, PT_WAVES))) k_ptrace(DScene sc, TraceIO io, unsigned long long *ctrs) {
     __shared__ int s_stack[LDS_STACK * TRACE_TPB];
     unsigned tn = 0, ti = 0;
     persistent_trace<ANY, COUNT>(sc, io, &s_stack[threadIdx.x], &tn, &ti);
@@ -331,6 +335,7 @@ struct PtrContext {
     /* pipeline */
     Lane lanes[N_LANES];
     int next_lane = 0, last_film_lane = -1;
+    int spread = 1; /* a ptr_render call deals its samples to this many passes (lanes) */
     int *api_fetch = nullptr; /* ray-fetch cursors of the stand-alone trace entry points (rotating) */
     int api_fetch_next = 0;
     int persist_blocks = 1024;
@@ -632,7 +637,15 @@ int ptr_create(int device, PtrContext **out) {
         return set_err(PTR_ERR_HIP, "context setup failed (hipMalloc / stream / event)");
     }
     /* persistent grid: enough 256-thread blocks to fill every CU at the tracer's occupancy */
-    ctx->persist_blocks = prop.multiProcessorCount * 4;
+    ctx->persist_blocks = prop.multiProcessorCount * PT_WAVES;
+    if (const char *e = getenv("PTR_SPREAD")) { /* tuning experiments */
+        int v = atoi(e);
+        if (v > 0) ctx->spread = v;
+    }
+    if (const char *e = getenv("PTR_PERSIST_BLOCKS")) { /* tuning experiments */
+        int v = atoi(e);
+        if (v > 0) ctx->persist_blocks = v;
+    }
     *out = ctx;
     return PTR_OK;
 }
@@ -760,7 +773,14 @@ int ptr_film_init(PtrContext *ctx, int width, int height, uint64_t seed) {
     int npix = width * height;
     if (!ctx->has_film || npix != ctx->npix) {
         free_film(ctx);
-        int nb = (1 << 22) / npix;
+        /* samples per pass: launches last as long as their longest ray (~2 ms on config[1]) while
+         * the marginal cost is ~0.25 ns per ray, so a pass should carry ~16 M path slots */
+        long long target = 1ll << 24;
+        if (const char *e = getenv("PTR_PASS_SLOTS")) { /* tuning experiments */
+            long long v = atoll(e);
+            if (v > 0) target = v;
+        }
+        int nb = (int)(target / npix);
         if (nb < 1) nb = 1;
         if (nb > 64) nb = 64;
         size_t cap = (size_t)npix * nb;
@@ -821,7 +841,7 @@ int ptr_render(PtrContext *ctx, int ns, int integrator) {
     while (first < end) {
         int remaining = (end - first + stride - 1) / stride;
         /* spread the samples of this call over the lanes before filling a lane's batch */
-        int nb = (remaining + N_LANES - 1) / N_LANES;
+        int nb = (remaining + ctx->spread - 1) / ctx->spread;
         if (nb > ctx->nb_max) nb = ctx->nb_max;
         if (nb < 1) nb = 1;
         int li = ctx->next_lane++ % N_LANES;
