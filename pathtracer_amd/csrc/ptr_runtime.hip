@@ -155,7 +155,10 @@ __global__ void __launch_bounds__(TRACE_TPB) __attribute__((amdgpu_waves_per_eu(
         const int i = base_ + (threadIdx.x & 63);
 #define GRID_STRIDE_END }
 
-__global__ void __launch_bounds__(TPB) k_shade(DScene sc, Pipe pp, PassParams prm, const int *n_ptr, int n_host, const int *queue,
+#ifndef SHADE_WAVES
+#define SHADE_WAVES 2
+#endif
+__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(SHADE_WAVES, SHADE_WAVES))) k_shade(DScene sc, Pipe pp, PassParams prm, const int *n_ptr, int n_host, const int *queue,
                                                int *q_next, int *q_nee, int *q_shadow, int *q_mis, int *counts, unsigned long long *ctrs) {
     VertexCtr ctr;
     ctr.total = ctr.miss = ctr.surf = ctr.med = ctr.light = ctr.zero = 0;
@@ -261,6 +264,69 @@ __global__ void __launch_bounds__(TPB) k_nee_resolve(DScene sc, Pipe pp, const i
     ctr_flush(ctrs, C_ZERO, ctr.zero);
 }
 
+/* Finishes every path of the queue inside one launch: trace -> shade -> direct light -> ... until
+ * the path ends (the loop of Li_* itself, main.cpp:105-410, one path per lane).  Used once the
+ * wavefront stages have thinned the pass to a few per cent of its paths: from there on a bounce
+ * is worth ~1e4 rays but would still cost three launches that each last as long as their longest
+ * ray.  Same device functions, same order of operations per path as the staged kernels. */
+__global__ void __launch_bounds__(TPB) k_finish(DScene sc, Pipe pp, PassParams prm, const int *n_ptr, int n_host, const int *queue, int walk,
+                                                unsigned long long *ctrs) {
+    __shared__ int s_stack[LDS_STACK * TRACE_TPB];
+    LaneStack ls;
+    ls.lds = &s_stack[threadIdx.x];
+    VertexCtr ctr;
+    ctr.total = ctr.miss = ctr.surf = ctr.med = ctr.light = ctr.zero = 0;
+    NeeCtr nctr;
+    nctr.shadow = nctr.mis = nctr.zero = 0;
+    GRID_STRIDE_BEGIN(n_ptr, n_host)
+    if (i < n) {
+        const int slot = queue ? queue[i] : i;
+        const int cap = pp.cap;
+        PathRec ps = pp.paths[slot];
+        f3 ro(pp.ro[slot], pp.ro[cap + slot], pp.ro[2 * cap + slot]);
+        f3 rd(pp.rd[slot], pp.rd[cap + slot], pp.rd[2 * cap + slot]);
+        Rng rng = make_rng(prm.seed, (uint32_t)(slot % prm.npix), (uint32_t)(prm.sample_first + (slot / prm.npix) * prm.sample_step));
+        rng.dim = (uint32_t)ps.dim;
+        f3 L = ld3(ps.L), beta = ld3(ps.beta);
+        int med = ps.medium, bounces = ps.bounces, pflags = ps.flags;
+        NeeRec *rec = &pp.nee[slot];
+        for (int guard = 0; guard < 100000; guard++) {
+            float tmax = kInfinity, b0 = 0, b1 = 0;
+            int hp = -1, hf = -1;
+            bool hit = traverse<false, false>(sc, ro, rd, tmax, hp, hf, b0, b1, nullptr, ls);
+            VertexOut vo = shade_vertex(sc, prm.integrator, rng, ro, rd, med, hit ? hp : -1, hit ? hf : -1, tmax, L, beta, bounces, pflags, rec, ctr);
+            if (vo.want_nee) {
+                f3 Ld;
+                if (walk) {
+                    if (rec->flags & NEE_A) nee_shadow<true>(sc, rec, nctr, ls);
+                    Ld = nee_mis_resolve<true>(sc, *rec, nctr, ls);
+                } else {
+                    if (rec->flags & NEE_A) nee_shadow<false>(sc, rec, nctr, ls);
+                    Ld = nee_mis_resolve<false>(sc, *rec, nctr, ls);
+                }
+                L += Ld;
+            }
+            if (!vo.alive) break;
+        }
+        st3(ps.L, L);
+        st3(ps.beta, beta);
+        ps.medium = med;
+        ps.bounces = bounces;
+        ps.flags = pflags;
+        ps.dim = (int)rng.dim;
+        pp.paths[slot] = ps;
+    }
+    GRID_STRIDE_END
+    ctr_flush(ctrs, C_TOTAL, ctr.total);
+    ctr_flush(ctrs, C_MISS, ctr.miss);
+    ctr_flush(ctrs, C_SURF, ctr.surf);
+    ctr_flush(ctrs, C_MED, ctr.med);
+    ctr_flush(ctrs, C_LIGHT, ctr.light);
+    ctr_flush(ctrs, C_ZERO, ctr.zero + nctr.zero);
+    ctr_flush(ctrs, C_SHADOW, nctr.shadow);
+    ctr_flush(ctrs, C_MIS, nctr.mis);
+}
+
 /* Render()'s accumulation (main.cpp:449-455): we += weight * L per sample, in sample order */
 __global__ void __launch_bounds__(TPB) k_film(Pipe pp, int npix, int nbatch, float *we, double *acc, long long *samples) {
     int p = blockIdx.x * TPB + threadIdx.x;
@@ -291,9 +357,9 @@ static int set_err(int code, const std::string &msg) {
         if (e_ != hipSuccess) return set_err(PTR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-enum { K_RAYGEN = 0, K_TRACE, K_SHADE, K_SHADOW, K_MIS, K_RESOLVE, K_FILM, K_API_TRACE };
+enum { K_RAYGEN = 0, K_TRACE, K_SHADE, K_SHADOW, K_MIS, K_RESOLVE, K_FILM, K_FINISH, K_API_TRACE = K_TRACE };
 static const char *kKernelNames[PTR_PROF_KERNELS] = {"raygen", "trace_closest", "shade", "nee_shadow", "nee_mis", "nee_resolve", "film",
-                                                     "api_trace"};
+                                                     "finish"};
 
 struct ProfSpan {
     hipEvent_t a, b;
@@ -312,8 +378,9 @@ struct Lane {
     Pipe pipe;
     int *queues[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int *counts = nullptr;      /* device: [MAX_ITERS][4] = next, nee, shadow, mis; then [MAX_ITERS][3] ray-fetch cursors */
-    int *counts_host = nullptr; /* pinned, 4 ints */
+    int *counts_host = nullptr; /* pinned: the [MAX_ITERS][4] counts of the last finished pass */
     hipEvent_t film_done = nullptr, joined = nullptr;
+    int staged_used = 0, slots_used = 0; /* of the pass last queued on this lane */
 };
 
 struct PtrContext {
@@ -335,6 +402,8 @@ struct PtrContext {
     /* pipeline */
     Lane lanes[N_LANES];
     int next_lane = 0, last_film_lane = -1;
+    int staged_bounces = 6; /* wavefront bounces before k_finish; adapted from the live counts of finished passes */
+    bool staged_fixed = false;
     int spread = 1; /* a ptr_render call deals its samples to this many passes (lanes) */
     int *api_fetch = nullptr; /* ray-fetch cursors of the stand-alone trace entry points (rotating) */
     int api_fetch_next = 0;
@@ -545,6 +614,15 @@ static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int ste
     prm.integrator = integrator;
     hipStream_t s = l.stream;
     const int slots = ctx->npix * nb;
+    /* feedback: if the pass this lane ran before has completed, look at how fast it thinned out and
+     * stage bounces only while more than ~0.4 % of the paths are alive */
+    if (!ctx->staged_fixed && l.staged_used > 0 && hipEventQuery(l.film_done) == hipSuccess) {
+        const int *hc = l.counts_host; /* copied (async, pinned) at the end of that pass */
+        int k = 0;
+        while (k < l.staged_used && hc[4 * k] > l.slots_used / 256) k++;
+        /* all staged bounces were still wide: stage one more next time */
+        ctx->staged_bounces = k < l.staged_used ? k + 1 : l.staged_used + 1;
+    }
     const size_t cbytes = (size_t)(7 * MAX_ITERS) * sizeof(int);
     HIPCHK(hipMemsetAsync(l.counts, 0, cbytes, s));
     {
@@ -553,39 +631,34 @@ static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int ste
     }
     ctx->camera_rays += (uint64_t)slots;
 
-    /* Bounces a path can take: Li_Direct 1; Li_Path bounces 0..9; Li_PathSampled 0..10 and
-     * Li_VolPath 0..15 (the vertex at max_bounces still adds emission, main.cpp:183,289).  Crossing
-     * a medium boundary without material does not count as a bounce (main.cpp:187-191), so scenes
-     * with such primitives have no bound and take the synchronous loop below. */
-    const int fixed_iters = integrator == PTR_LI_DIRECT ? 1 : integrator == PTR_LI_PATH ? 10 : integrator == PTR_LI_PATHSAMPLED ? 11 : 16;
+    /* Staged bounces while the pass is wide, then one launch that runs the survivors to their end
+     * (no bound on path length is needed: media boundaries without material do not count as
+     * bounces, main.cpp:187-191).  No host round trip: every launch reads its count from the
+     * counter block the previous bounce wrote; grids are sized from an estimate and stride over
+     * whatever is there. */
+    const int max_iters = integrator == PTR_LI_DIRECT ? 1 : integrator == PTR_LI_PATH ? 10 : integrator == PTR_LI_PATHSAMPLED ? 11 : 16;
+    int staged = ctx->staged_bounces < max_iters ? ctx->staged_bounces : max_iters;
+    if (staged < 1) staged = 1;
+    if (staged > MAX_ITERS) staged = MAX_ITERS;
     const int *q_cur = nullptr; /* identity */
     int qi = 0;
-    if (!ctx->scene_passthrough) {
-        /* no host round trip: every launch reads its count from the counter block the previous
-         * bounce wrote; grids are sized from an estimate and stride over whatever is there */
-        for (int k = 0; k < fixed_iters; k++) {
-            int *q_next = l.queues[qi];
-            int upper = slots >> (k < 6 ? k : 6);
-            if (upper < 1) upper = 1;
-            enqueue_bounce(ctx, l, prm, k == 0 ? nullptr : l.counts + 4 * (k - 1), slots, k == 0 ? slots : upper, q_cur, q_next, k);
-            q_cur = q_next;
-            qi ^= 1;
-        }
-    } else {
-        int n_cur = slots;
-        for (int iter = 0; n_cur > 0 && iter < 65536; iter++) {
-            int *q_next = l.queues[qi];
-            const int cslot = iter % MAX_ITERS;
-            if (iter >= MAX_ITERS) HIPCHK(hipMemsetAsync(l.counts + 4 * cslot, 0, 4 * sizeof(int), s));
-            if (iter >= MAX_ITERS) HIPCHK(hipMemsetAsync(l.counts + 4 * MAX_ITERS + 3 * cslot, 0, 3 * sizeof(int), s));
-            enqueue_bounce(ctx, l, prm, nullptr, n_cur, n_cur, q_cur, q_next, cslot);
-            HIPCHK(hipMemcpyAsync(l.counts_host, l.counts + 4 * cslot, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
-            HIPCHK(hipStreamSynchronize(s));
-            n_cur = l.counts_host[0];
-            q_cur = q_next;
-            qi ^= 1;
-        }
+    for (int k = 0; k < staged; k++) {
+        int *q_next = l.queues[qi];
+        int upper = slots >> (k < 6 ? k : 6);
+        if (upper < 1) upper = 1;
+        enqueue_bounce(ctx, l, prm, k == 0 ? nullptr : l.counts + 4 * (k - 1), slots, k == 0 ? slots : upper, q_cur, q_next, k);
+        q_cur = q_next;
+        qi ^= 1;
     }
+    if (integrator != PTR_LI_DIRECT) {
+        const bool walk = integrator == PTR_LI_VOLPATH && !ctx->scene_all_opaque;
+        int upper = slots >> (staged < 6 ? staged : 6);
+        ProfScope ps(ctx, s, K_FINISH, 0);
+        hipLaunchKernelGGL(k_finish, dim3(clampu(nblocks(upper), 32, 2048)), dim3(TPB), 0, s, ctx->sc, l.pipe, prm,
+                           (const int *)(l.counts + 4 * (staged - 1)), 0, q_cur, walk ? 1 : 0, ctx->ctrs);
+    }
+    l.staged_used = staged;
+    l.slots_used = slots;
     /* the film is accumulated in sample order: this pass's film kernel follows the previous one's */
     if (ctx->last_film_lane >= 0 && ctx->last_film_lane != lane_index)
         HIPCHK(hipStreamWaitEvent(s, ctx->lanes[ctx->last_film_lane].film_done, 0));
@@ -593,6 +666,7 @@ static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int ste
         ProfScope ps(ctx, s, K_FILM, (uint64_t)ctx->npix);
         hipLaunchKernelGGL(k_film, dim3(nblocks(ctx->npix)), dim3(TPB), 0, s, l.pipe, ctx->npix, nb, ctx->we, ctx->acc, ctx->samples);
     }
+    HIPCHK(hipMemcpyAsync(l.counts_host, l.counts, 4 * MAX_ITERS * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipEventRecord(l.film_done, s));
     ctx->last_film_lane = lane_index;
     HIPCHK(hipGetLastError());
@@ -638,6 +712,10 @@ int ptr_create(int device, PtrContext **out) {
     }
     /* persistent grid: enough 256-thread blocks to fill every CU at the tracer's occupancy */
     ctx->persist_blocks = prop.multiProcessorCount * PT_WAVES;
+    if (const char *e = getenv("PTR_STAGED")) { /* tuning experiments: fixed number of staged bounces */
+        int v = atoi(e);
+        if (v > 0) { ctx->staged_bounces = v; ctx->staged_fixed = true; }
+    }
     if (const char *e = getenv("PTR_SPREAD")) { /* tuning experiments */
         int v = atoi(e);
         if (v > 0) ctx->spread = v;
@@ -799,7 +877,7 @@ int ptr_film_init(PtrContext *ctx, int width, int height, uint64_t seed) {
             HIPCHK(hipMalloc((void **)&l.pipe.nee, sizeof(NeeRec) * cap));
             for (int q = 0; q < 5; q++) HIPCHK(hipMalloc((void **)&l.queues[q], sizeof(int) * cap));
             HIPCHK(hipMalloc((void **)&l.counts, 7 * MAX_ITERS * sizeof(int)));
-            HIPCHK(hipHostMalloc((void **)&l.counts_host, 4 * sizeof(int), hipHostMallocDefault));
+            HIPCHK(hipHostMalloc((void **)&l.counts_host, 4 * MAX_ITERS * sizeof(int), hipHostMallocDefault));
             l.pipe.cap = (int)cap;
         }
     }
