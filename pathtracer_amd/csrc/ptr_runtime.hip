@@ -158,6 +158,53 @@ __global__ void __launch_bounds__(TRACE_TPB) __attribute__((amdgpu_waves_per_eu(
 #ifndef SHADE_WAVES
 #define SHADE_WAVES 2
 #endif
+/* ---- bin the live paths by what they hit, so that a wavefront of k_shade runs one material's code
+ * (miss / emitter / no material / the ten material types): two streaming passes, count then
+ * scatter, wave-aggregated atomics per class.  The arithmetic of a path does not depend on where
+ * in the queue it sits. */
+#define N_CLASSES 16
+PD int shade_class(const DScene &sc, int hp) {
+    if (hp < 0) return 0;
+    const DPrim &pr = sc.prims[hp];
+    if (pr.flags & PF_EMISSIVE) return 1;
+    if (pr.material < 0) return 2;
+    int t = sc.mats[pr.material].type;
+    return 3 + (t < 0 ? 0 : (t > 12 ? 12 : t));
+}
+__global__ void __launch_bounds__(TPB) k_bin_count(DScene sc, Pipe pp, const int *n_ptr, int n_host, const int *queue, int *cls_count) {
+    GRID_STRIDE_BEGIN(n_ptr, n_host)
+    int cls = -1;
+    if (i < n) cls = shade_class(sc, pp.hprim[queue ? queue[i] : i]);
+    for (int c = 0; c < N_CLASSES; c++) {
+        unsigned long long m = __ballot(cls == c);
+        if (m && __lane_id() == __ffsll((long long)m) - 1) atomicAdd(&cls_count[c], __popcll(m));
+    }
+    GRID_STRIDE_END
+}
+__global__ void __launch_bounds__(TPB) k_bin_scatter(DScene sc, Pipe pp, const int *n_ptr, int n_host, const int *queue, const int *cls_count,
+                                                     int *cls_cursor, int *q_out) {
+    GRID_STRIDE_BEGIN(n_ptr, n_host)
+    int cls = -1, slot = 0;
+    if (i < n) {
+        slot = queue ? queue[i] : i;
+        cls = shade_class(sc, pp.hprim[slot]);
+    }
+    int start = 0; /* first index of my class in the output */
+    for (int c = 0; c < N_CLASSES; c++) {
+        int cnt = cls_count[c];
+        unsigned long long m = __ballot(cls == c);
+        if (m) {
+            int leader = __ffsll((long long)m) - 1;
+            int base = 0;
+            if (__lane_id() == leader) base = atomicAdd(&cls_cursor[c], __popcll(m));
+            base = __shfl(base, leader, 64);
+            if (cls == c) q_out[start + base + __popcll(m & ((1ull << __lane_id()) - 1ull))] = slot;
+        }
+        start += cnt;
+    }
+    GRID_STRIDE_END
+}
+
 __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(SHADE_WAVES, SHADE_WAVES))) k_shade(DScene sc, Pipe pp, PassParams prm, const int *n_ptr, int n_host, const int *queue,
                                                int *q_next, int *q_nee, int *q_shadow, int *q_mis, int *counts, unsigned long long *ctrs) {
     VertexCtr ctr;
@@ -373,11 +420,13 @@ struct ProfSpan {
  * of one overlaps the bulk of the others. */
 #define N_LANES 4
 #define MAX_ITERS 20
+#define LANE_COUNTER_INTS ((7 + 2 * 16) * MAX_ITERS)
 struct Lane {
     hipStream_t stream = nullptr;
     Pipe pipe;
-    int *queues[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    int *counts = nullptr;      /* device: [MAX_ITERS][4] = next, nee, shadow, mis; then [MAX_ITERS][3] ray-fetch cursors */
+    int *queues[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; /* ping, pong, nee, shadow, mis, binned */
+    int *counts = nullptr;      /* device: [MAX_ITERS][4] = next, nee, shadow, mis; [MAX_ITERS][3] ray-fetch cursors;
+                                   [MAX_ITERS][2][N_CLASSES] class counts and scatter cursors */
     int *counts_host = nullptr; /* pinned: the [MAX_ITERS][4] counts of the last finished pass */
     hipEvent_t film_done = nullptr, joined = nullptr;
     int staged_used = 0, slots_used = 0; /* of the pass last queued on this lane */
@@ -404,6 +453,8 @@ struct PtrContext {
     int next_lane = 0, last_film_lane = -1;
     int staged_bounces = 6; /* wavefront bounces before k_finish; adapted from the live counts of finished passes */
     bool staged_fixed = false;
+    bool bin_by_material = false; /* measured on config[1]: the two extra passes and the loss of slot-order locality cost more
+                                     than the divergence they remove (725 vs 875 Mrays/s); kept for experiments (PTR_BIN=1) */
     int spread = 1; /* a ptr_render call deals its samples to this many passes (lanes) */
     int *api_fetch = nullptr; /* ray-fetch cursors of the stand-alone trace entry points (rotating) */
     int api_fetch_next = 0;
@@ -454,12 +505,12 @@ static void free_film(PtrContext *ctx) {
     ctx->we = nullptr; ctx->acc = nullptr; ctx->samples = nullptr;
     for (Lane &l : ctx->lanes) {
         void *ptrs[] = {l.pipe.ro, l.pipe.rd, l.pipe.hprim, l.pipe.hface, l.pipe.ht, l.pipe.paths, l.pipe.nee,
-                        l.queues[0], l.queues[1], l.queues[2], l.queues[3], l.queues[4], l.counts};
+                        l.queues[0], l.queues[1], l.queues[2], l.queues[3], l.queues[4], l.queues[5], l.counts};
         for (void *p : ptrs)
             if (p) (void)hipFree(p);
         if (l.counts_host) (void)hipHostFree(l.counts_host);
         memset(&l.pipe, 0, sizeof(l.pipe));
-        for (int q = 0; q < 5; q++) l.queues[q] = nullptr;
+        for (int q = 0; q < 6; q++) l.queues[q] = nullptr;
         l.counts = nullptr;
         l.counts_host = nullptr;
     }
@@ -553,9 +604,18 @@ static void enqueue_bounce(PtrContext *ctx, Lane &l, const PassParams &prm, cons
         io.counter = fetch + 0;
         launch_ptrace(ctx, s, io, n_upper, false, ctx->count_traversal, K_TRACE);
     }
+    const int *q_shade = q_cur;
+    if (ctx->bin_by_material) {
+        int *cls = l.counts + 7 * MAX_ITERS + 2 * N_CLASSES * cslot;
+        ProfScope ps(ctx, s, K_SHADE, 0);
+        hipLaunchKernelGGL(k_bin_count, dim3(stride_blocks), dim3(TPB), 0, s, ctx->sc, l.pipe, n_ptr, n_host, q_cur, cls);
+        hipLaunchKernelGGL(k_bin_scatter, dim3(stride_blocks), dim3(TPB), 0, s, ctx->sc, l.pipe, n_ptr, n_host, q_cur, (const int *)cls,
+                           cls + N_CLASSES, l.queues[5]);
+        q_shade = l.queues[5];
+    }
     {
         ProfScope ps(ctx, s, K_SHADE, (uint64_t)(n_ptr ? 0 : n_host));
-        hipLaunchKernelGGL(k_shade, dim3(stride_blocks), dim3(TPB), 0, s, ctx->sc, l.pipe, prm, n_ptr, n_host, q_cur, q_next, q_nee, q_shadow, q_mis,
+        hipLaunchKernelGGL(k_shade, dim3(stride_blocks), dim3(TPB), 0, s, ctx->sc, l.pipe, prm, n_ptr, n_host, q_shade, q_next, q_nee, q_shadow, q_mis,
                            cnt, ctx->ctrs);
     }
     /* the walks of VisibilityTester::Tr / IntersectTr can only go past their first hit under
@@ -623,7 +683,7 @@ static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int ste
         /* all staged bounces were still wide: stage one more next time */
         ctx->staged_bounces = k < l.staged_used ? k + 1 : l.staged_used + 1;
     }
-    const size_t cbytes = (size_t)(7 * MAX_ITERS) * sizeof(int);
+    const size_t cbytes = (size_t)LANE_COUNTER_INTS * sizeof(int);
     HIPCHK(hipMemsetAsync(l.counts, 0, cbytes, s));
     {
         ProfScope ps(ctx, s, K_RAYGEN, (uint64_t)slots);
@@ -716,6 +776,7 @@ int ptr_create(int device, PtrContext **out) {
         int v = atoi(e);
         if (v > 0) { ctx->staged_bounces = v; ctx->staged_fixed = true; }
     }
+    if (const char *e = getenv("PTR_BIN")) ctx->bin_by_material = atoi(e) != 0; /* tuning experiments */
     if (const char *e = getenv("PTR_SPREAD")) { /* tuning experiments */
         int v = atoi(e);
         if (v > 0) ctx->spread = v;
@@ -875,8 +936,8 @@ int ptr_film_init(PtrContext *ctx, int width, int height, uint64_t seed) {
             HIPCHK(hipMalloc((void **)&l.pipe.ht, sizeof(float) * cap));
             HIPCHK(hipMalloc((void **)&l.pipe.paths, sizeof(PathRec) * cap));
             HIPCHK(hipMalloc((void **)&l.pipe.nee, sizeof(NeeRec) * cap));
-            for (int q = 0; q < 5; q++) HIPCHK(hipMalloc((void **)&l.queues[q], sizeof(int) * cap));
-            HIPCHK(hipMalloc((void **)&l.counts, 7 * MAX_ITERS * sizeof(int)));
+            for (int q = 0; q < 6; q++) HIPCHK(hipMalloc((void **)&l.queues[q], sizeof(int) * cap));
+            HIPCHK(hipMalloc((void **)&l.counts, LANE_COUNTER_INTS * sizeof(int)));
             HIPCHK(hipHostMalloc((void **)&l.counts_host, 4 * MAX_ITERS * sizeof(int), hipHostMallocDefault));
             l.pipe.cap = (int)cap;
         }
