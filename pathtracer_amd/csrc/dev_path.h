@@ -71,6 +71,25 @@ struct __attribute__((aligned(16))) NeeRec {
 PD void st3(float *d, const f3 &v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; }
 PD f3 ld3(const float *s) { return f3(s[0], s[1], s[2]); }
 
+/* Where build_nee leaves the record it makes: NeeToStruct fills a NeeRec in registers (finish
+ * kernel), NeeToPlanes stores each word straight into its plane in HBM (shade kernel: word w of
+ * slot s at base[w * cap + s], a coalesced store per field and nothing kept in registers). */
+#define NEE_W(field) ((int)(offsetof(NeeRec, field) / 4))
+struct NeeToStruct {
+    NeeRec *r;
+    PD void put(int w, float v) const { reinterpret_cast<float *>(r)[w] = v; }
+    PD void puti(int w, int v) const { reinterpret_cast<int *>(r)[w] = v; }
+    PD void put3(int w, const f3 &v) const { put(w, v.x); put(w + 1, v.y); put(w + 2, v.z); }
+};
+struct NeeToPlanes {
+    float *base;
+    size_t cap;
+    int slot;
+    PD void put(int w, float v) const { base[w * cap + slot] = v; }
+    PD void puti(int w, int v) const { base[w * cap + slot] = __int_as_float(v); }
+    PD void put3(int w, const f3 &v) const { put(w, v.x); put(w + 1, v.y); put(w + 2, v.z); }
+};
+
 struct VertexCtr { unsigned total, miss, surf, med, light, zero; };
 
 /* Interaction::SpawnRayTo, interaction.cpp:11-21 */
@@ -85,8 +104,9 @@ PD void spawn_ray_to(const f3 &p, const f3 &pErr, const f3 &n, int med_in, int m
 /* EstimateDirect up to the two scene queries (primitive.cpp:246-339): everything that does not
  * need a ray is evaluated here, the queries themselves are left to the nee kernel.
  * Returns false if neither half has anything to trace. */
-PD bool build_nee(const DScene &sc, const Ref &it, const BSDF *bsdf, float phase_g, const f2 &u2, const f3 &u3, bool handleMedium,
-                  const f3 &beta, bool countZero, NeeRec *rec) {
+template <class NeeSink>
+PD int build_nee(const DScene &sc, const Ref &it, const BSDF *bsdf, float phase_g, const f2 &u2, const f3 &u3, bool handleMedium,
+                  const f3 &beta, bool countZero, const NeeSink &rec) {
     int nLights = sc.n_lights;
     int lightNum = (int)fminr((float)(int)(u2.x * nLights), (float)(nLights - 1));
     f2 uLight(u2.y, u3.x);
@@ -110,19 +130,19 @@ PD bool build_nee(const DScene &sc, const Ref &it, const BSDF *bsdf, float phase
         }
         if (!is_black(f)) {
             flags |= NEE_A;
-            st3(rec->fA, f);
-            st3(rec->LiA, Li);
-            rec->wA = power_heuristic(1, lightPdf, 1, scatteringPdf);
-            rec->pdfA = lightPdf;
+            rec.put3(NEE_W(fA), f);
+            rec.put3(NEE_W(LiA), Li);
+            rec.put(NEE_W(wA), power_heuristic(1, lightPdf, 1, scatteringPdf));
+            rec.put(NEE_W(pdfA), lightPdf);
             f3 o, d;
             int med;
             spawn_ray_to(it.p, it.pError, it.n, it.med_in, it.med_out, p1, &o, &d, &med);
-            st3(rec->oA, o);
-            st3(rec->dA, d);
-            rec->medA = med;
-            st3(rec->p1, p1.p);
-            st3(rec->p1err, p1.pError);
-            st3(rec->p1n, p1.n);
+            rec.put3(NEE_W(oA), o);
+            rec.put3(NEE_W(dA), d);
+            rec.puti(NEE_W(medA), med);
+            rec.put3(NEE_W(p1), p1.p);
+            rec.put3(NEE_W(p1err), p1.pError);
+            rec.put3(NEE_W(p1n), p1.n);
         }
     }
     {
@@ -148,37 +168,40 @@ PD bool build_nee(const DScene &sc, const Ref &it, const BSDF *bsdf, float phase
             }
             if (ok) {
                 flags |= NEE_B;
-                st3(rec->fB, f);
-                rec->wB = weight;
-                rec->pdfB = scatteringPdf;
-                st3(rec->oB, offset_ray_origin(it.p, it.pError, it.n, wi));
-                st3(rec->dB, wi);
-                rec->medB = ref_medium(it, wi);
-                rec->light = lightNum;
+                rec.put3(NEE_W(fB), f);
+                rec.put(NEE_W(wB), weight);
+                rec.put(NEE_W(pdfB), scatteringPdf);
+                rec.put3(NEE_W(oB), offset_ray_origin(it.p, it.pError, it.n, wi));
+                rec.put3(NEE_W(dB), wi);
+                rec.put(NEE_W(medB), ref_medium(it, wi));
+                rec.puti(NEE_W(light), lightNum);
             }
         }
     }
-    if (!(flags & (NEE_A | NEE_B))) return false;
+    if (!(flags & (NEE_A | NEE_B))) return 0;
     if (handleMedium) flags |= NEE_MEDIUM;
     if (countZero) flags |= NEE_COUNT_ZERO;
-    rec->flags = flags;
-    st3(rec->beta, beta);
-    return true;
+    rec.puti(NEE_W(flags), flags);
+    rec.put3(NEE_W(beta), beta);
+    return flags;
 }
 
 /* What one vertex hands back to the kernel */
 struct VertexOut {
     bool alive;    /* the path continues with the ray written to (ro, rd, medium) */
-    bool want_nee; /* *rec was filled */
+    bool want_nee; /* the record was filled */
+    int nee_flags; /* its flags (NEE_A: shadow ray, NEE_B: MIS ray) */
 };
 
 /* One loop iteration of Li_Direct / Li_Path / Li_PathSampled / Li_VolPath (main.cpp:72-410).
  * On entry (ro, rd) is the ray that was traced and (hp, hf, ht) its closest hit (hp < 0: miss). */
+template <class NeeSink>
 PD VertexOut shade_vertex(const DScene &sc, int integrator, Rng &rng, f3 &ro, f3 &rd, int &ray_medium, int hp, int hf, float ht, f3 &L,
-                          f3 &beta, int &bounces, int &pflags, NeeRec *rec, VertexCtr &ctr) {
+                          f3 &beta, int &bounces, int &pflags, const NeeSink &rec, VertexCtr &ctr) {
     VertexOut out;
     out.alive = false;
     out.want_nee = false;
+    out.nee_flags = 0;
     const bool found = hp >= 0;
     SI si;
     BSDF bsdf;
@@ -197,7 +220,7 @@ PD VertexOut shade_vertex(const DScene &sc, int integrator, Rng &rng, f3 &ro, f3
         if (sc.n_lights > 0) {
             f2 u2 = rand2(rng);
             f3 u3 = rand3(rng);
-            out.want_nee = build_nee(sc, ref_from_si(si), &bsdf, 0, u2, u3, false, f3(1.f), false, rec);
+            { out.nee_flags = build_nee(sc, ref_from_si(si), &bsdf, 0, u2, u3, false, f3(1.f), false, rec); out.want_nee = out.nee_flags != 0; }
         }
         return out;
     }
@@ -269,7 +292,7 @@ PD VertexOut shade_vertex(const DScene &sc, int integrator, Rng &rng, f3 &ro, f3
             f2 u2 = rand2(rng);
             f3 u3 = rand3(rng);
             if (sc.n_lights < 1) ctr.zero++;
-            else out.want_nee = build_nee(sc, it, nullptr, g, u2, u3, true, beta, true, rec);
+            else { out.nee_flags = build_nee(sc, it, nullptr, g, u2, u3, true, beta, true, rec); out.want_nee = out.nee_flags != 0; }
             if (sc.n_lights >= 1 && !out.want_nee) ctr.zero++;
             f3 wo = -rd, wi;
             u2 = rand2(rng);
@@ -305,7 +328,7 @@ PD VertexOut shade_vertex(const DScene &sc, int integrator, Rng &rng, f3 &ro, f3
             f3 u3 = rand3(rng);
             if (sc.n_lights < 1) ctr.zero++;
             else {
-                out.want_nee = build_nee(sc, it, &bsdf, 0, u2, u3, vol, beta, true, rec);
+                { out.nee_flags = build_nee(sc, it, &bsdf, 0, u2, u3, vol, beta, true, rec); out.want_nee = out.nee_flags != 0; }
                 if (!out.want_nee) ctr.zero++;
             }
         }

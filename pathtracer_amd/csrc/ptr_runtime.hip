@@ -33,8 +33,8 @@ struct Pipe {
     float *ro, *rd;      /* 3 planes of cap floats each */
     int *hprim, *hface;
     float *ht;
-    PathRec *paths;
-    NeeRec *nee;
+    uint32_t *paths; /* PathRec as PATH_WORDS planes of cap words: word w of slot s at paths[w * cap + s] */
+    uint32_t *nee;   /* NeeRec as NEE_WORDS planes */
     int cap;
 };
 struct PassParams {
@@ -43,6 +43,35 @@ struct PassParams {
     int sample_first, sample_step; /* sample of slot = sample_first + (slot / npix) * sample_step */
     int integrator;
 };
+
+
+/* Path and direct-light records live in HBM as planes of 32-bit words (structure of arrays):
+ * consecutive lanes work on consecutive slots, so every load / store of a field is one coalesced
+ * request per wavefront; in registers a record is the plain struct. */
+#define PATH_WORDS ((int)(sizeof(PathRec) / 4))
+#define NEE_WORDS ((int)(sizeof(NeeRec) / 4))
+#define WORD_OF(T, field) ((int)(offsetof(T, field) / 4))
+template <int W0, int W1, typename T> PD void soa_load(const uint32_t *base, int cap, int slot, T *rec) {
+    uint32_t *o = reinterpret_cast<uint32_t *>(rec);
+#pragma unroll
+    for (int w = W0; w < W1; w++) o[w] = base[(size_t)w * cap + slot];
+}
+template <int W0, int W1, typename T> PD void soa_store(uint32_t *base, int cap, int slot, const T *rec) {
+    const uint32_t *o = reinterpret_cast<const uint32_t *>(rec);
+#pragma unroll
+    for (int w = W0; w < W1; w++) base[(size_t)w * cap + slot] = o[w];
+}
+#define NEE_A_BEGIN WORD_OF(NeeRec, fA)
+#define NEE_A_END WORD_OF(NeeRec, fB)
+#define NEE_B_BEGIN WORD_OF(NeeRec, fB)
+#define NEE_B_END WORD_OF(NeeRec, occA)
+#define NEE_RES_BEGIN WORD_OF(NeeRec, occA)
+#define NEE_RES_END (WORD_OF(NeeRec, tB) + 1)
+PD void nee_load(const Pipe &pp, int slot, NeeRec *rec) { /* header, then only the halves in use */
+    soa_load<0, 4>(pp.nee, pp.cap, slot, rec);
+    if (rec->flags & NEE_A) soa_load<NEE_A_BEGIN, NEE_A_END>(pp.nee, pp.cap, slot, rec);
+    if (rec->flags & NEE_B) soa_load<NEE_B_BEGIN, NEE_B_END>(pp.nee, pp.cap, slot, rec);
+}
 
 __device__ __forceinline__ unsigned wave_sum(unsigned v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -117,7 +146,7 @@ __global__ void __launch_bounds__(TPB) k_raygen(DScene sc, DCamera cam, Pipe pp,
     ps.medium = sc.view_medium;
     ps.weight = w;
     ps.pad = 0;
-    pp.paths[slot] = ps;
+    soa_store<0, PATH_WORDS>(pp.paths, pp.cap, slot, &ps);
 }
 
 /* ray generation alone, SoA planes of n = npix (ptr_generate_rays) */
@@ -215,7 +244,9 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(SHADE_
     if (i < n) {
         slot = queue ? queue[i] : i;
         int cap = pp.cap;
-        PathRec ps = pp.paths[slot];
+        PathRec ps;
+        soa_load<0, PATH_WORDS>(pp.paths, cap, slot, &ps);
+        const NeeToPlanes rec = {reinterpret_cast<float *>(pp.nee), (size_t)cap, slot};
         f3 ro(pp.ro[slot], pp.ro[cap + slot], pp.ro[2 * cap + slot]);
         f3 rd(pp.rd[slot], pp.rd[cap + slot], pp.rd[2 * cap + slot]);
         int pixel = slot % prm.npix;
@@ -225,18 +256,18 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(SHADE_
         f3 L = ld3(ps.L), beta = ld3(ps.beta);
         int med = ps.medium, bounces = ps.bounces, pflags = ps.flags;
         VertexOut vo = shade_vertex(sc, prm.integrator, rng, ro, rd, med, pp.hprim[slot], pp.hface[slot], pp.ht[slot], L, beta, bounces,
-                                    pflags, &pp.nee[slot], ctr);
+                                    pflags, rec, ctr);
         alive = vo.alive;
         want_nee = vo.want_nee;
-        want_shadow = want_nee && (pp.nee[slot].flags & NEE_A);
-        want_mis = want_nee && (pp.nee[slot].flags & NEE_B);
+        want_shadow = want_nee && (vo.nee_flags & NEE_A);
+        want_mis = want_nee && (vo.nee_flags & NEE_B);
         st3(ps.L, L);
         st3(ps.beta, beta);
         ps.medium = med;
         ps.bounces = bounces;
         ps.flags = pflags;
         ps.dim = (int)rng.dim;
-        pp.paths[slot] = ps;
+        soa_store<0, WORD_OF(PathRec, weight)>(pp.paths, cap, slot, &ps);
         if (alive) {
             pp.ro[slot] = ro.x; pp.ro[cap + slot] = ro.y; pp.ro[2 * cap + slot] = ro.z;
             pp.rd[slot] = rd.x; pp.rd[cap + slot] = rd.y; pp.rd[2 * cap + slot] = rd.z;
@@ -265,7 +296,13 @@ __global__ void __launch_bounds__(TPB) k_shadow_walk(DScene sc, Pipe pp, const i
     NeeCtr ctr;
     ctr.shadow = ctr.mis = ctr.zero = 0;
     GRID_STRIDE_BEGIN(n_ptr, n_host)
-    if (i < n) nee_shadow<true>(sc, &pp.nee[queue[i]], ctr, ls);
+    if (i < n) {
+        const int slot = queue[i];
+        NeeRec rec;
+        nee_load(pp, slot, &rec);
+        nee_shadow<true>(sc, &rec, ctr, ls);
+        soa_store<WORD_OF(NeeRec, LiA), WORD_OF(NeeRec, LiA) + 3>(pp.nee, pp.cap, slot, &rec);
+    }
     GRID_STRIDE_END
     ctr_flush(ctrs, C_SHADOW, ctr.shadow);
 }
@@ -280,11 +317,15 @@ __global__ void __launch_bounds__(TPB) k_mis_walk(DScene sc, Pipe pp, const int 
     GRID_STRIDE_BEGIN(n_ptr, n_host)
     if (i < n) {
         int slot = queue[i];
-        f3 Ld = nee_mis_resolve<true>(sc, pp.nee[slot], ctr, ls);
-        PathRec *ps = &pp.paths[slot];
-        f3 L = ld3(ps->L);
+        NeeRec rec;
+        nee_load(pp, slot, &rec);
+        f3 Ld = nee_mis_resolve<true>(sc, rec, ctr, ls);
+        PathRec ps;
+        soa_load<0, 3>(pp.paths, pp.cap, slot, &ps);
+        f3 L = ld3(ps.L);
         L += Ld;
-        st3(ps->L, L);
+        st3(ps.L, L);
+        soa_store<0, 3>(pp.paths, pp.cap, slot, &ps);
     }
     GRID_STRIDE_END
     ctr_flush(ctrs, C_MIS, ctr.mis);
@@ -299,11 +340,16 @@ __global__ void __launch_bounds__(TPB) k_nee_resolve(DScene sc, Pipe pp, const i
     GRID_STRIDE_BEGIN(n_ptr, n_host)
     if (i < n) {
         int slot = queue[i];
-        f3 Ld = nee_resolve_traced(sc, pp.nee[slot], ctr);
-        PathRec *ps = &pp.paths[slot];
-        f3 L = ld3(ps->L);
+        NeeRec rec;
+        nee_load(pp, slot, &rec);
+        soa_load<NEE_RES_BEGIN, NEE_RES_END>(pp.nee, pp.cap, slot, &rec);
+        f3 Ld = nee_resolve_traced(sc, rec, ctr);
+        PathRec ps;
+        soa_load<0, 3>(pp.paths, pp.cap, slot, &ps);
+        f3 L = ld3(ps.L);
         L += Ld;
-        st3(ps->L, L);
+        st3(ps.L, L);
+        soa_store<0, 3>(pp.paths, pp.cap, slot, &ps);
     }
     GRID_STRIDE_END
     ctr_flush(ctrs, C_SHADOW, ctr.shadow);
@@ -329,19 +375,21 @@ __global__ void __launch_bounds__(TPB) k_finish(DScene sc, Pipe pp, PassParams p
     if (i < n) {
         const int slot = queue ? queue[i] : i;
         const int cap = pp.cap;
-        PathRec ps = pp.paths[slot];
+        PathRec ps;
+        soa_load<0, PATH_WORDS>(pp.paths, cap, slot, &ps);
         f3 ro(pp.ro[slot], pp.ro[cap + slot], pp.ro[2 * cap + slot]);
         f3 rd(pp.rd[slot], pp.rd[cap + slot], pp.rd[2 * cap + slot]);
         Rng rng = make_rng(prm.seed, (uint32_t)(slot % prm.npix), (uint32_t)(prm.sample_first + (slot / prm.npix) * prm.sample_step));
         rng.dim = (uint32_t)ps.dim;
         f3 L = ld3(ps.L), beta = ld3(ps.beta);
         int med = ps.medium, bounces = ps.bounces, pflags = ps.flags;
-        NeeRec *rec = &pp.nee[slot];
+        NeeRec rec_local;
+        NeeRec *rec = &rec_local;
         for (int guard = 0; guard < 100000; guard++) {
             float tmax = kInfinity, b0 = 0, b1 = 0;
             int hp = -1, hf = -1;
             bool hit = traverse<false, false>(sc, ro, rd, tmax, hp, hf, b0, b1, nullptr, ls);
-            VertexOut vo = shade_vertex(sc, prm.integrator, rng, ro, rd, med, hit ? hp : -1, hit ? hf : -1, tmax, L, beta, bounces, pflags, rec, ctr);
+            VertexOut vo = shade_vertex(sc, prm.integrator, rng, ro, rd, med, hit ? hp : -1, hit ? hf : -1, tmax, L, beta, bounces, pflags, NeeToStruct{rec}, ctr);
             if (vo.want_nee) {
                 f3 Ld;
                 if (walk) {
@@ -361,7 +409,7 @@ __global__ void __launch_bounds__(TPB) k_finish(DScene sc, Pipe pp, PassParams p
         ps.bounces = bounces;
         ps.flags = pflags;
         ps.dim = (int)rng.dim;
-        pp.paths[slot] = ps;
+        soa_store<0, WORD_OF(PathRec, weight)>(pp.paths, cap, slot, &ps);
     }
     GRID_STRIDE_END
     ctr_flush(ctrs, C_TOTAL, ctr.total);
@@ -381,7 +429,10 @@ __global__ void __launch_bounds__(TPB) k_film(Pipe pp, int npix, int nbatch, flo
     f3 out(we[3 * p], we[3 * p + 1], we[3 * p + 2]);
     double a = acc[p];
     for (int b = 0; b < nbatch; b++) {
-        const PathRec &ps = pp.paths[(size_t)b * npix + p];
+        PathRec ps;
+        const int slot = b * npix + p;
+        soa_load<0, 3>(pp.paths, pp.cap, slot, &ps);
+        soa_load<WORD_OF(PathRec, weight), WORD_OF(PathRec, weight) + 1>(pp.paths, pp.cap, slot, &ps);
         out += ps.weight * ld3(ps.L);
         a += ps.weight;
     }
@@ -631,15 +682,16 @@ static void enqueue_bounce(PtrContext *ctx, Lane &l, const PassParams &prm, cons
             hipLaunchKernelGGL(k_mis_walk, dim3(stride_blocks), dim3(TPB), 0, s, ctx->sc, l.pipe, (const int *)(cnt + 1), 0, (const int *)q_nee, ctx->ctrs);
         }
     } else {
-        NeeRec *nee = l.pipe.nee;
+        const char *nee = (const char *)l.pipe.nee;
+        const long long plane = 4ll * l.pipe.cap; /* bytes between the planes of consecutive words */
         { /* shadow rays: any hit within (0, 1 - ShadowEpsilon) */
             TraceIO io;
             memset(&io, 0, sizeof(io));
             io.queue = q_shadow; io.n_ptr = cnt + 2;
-            io.o = (const char *)nee + offsetof(NeeRec, oA); io.o_es = sizeof(NeeRec); io.o_cs = 4;
-            io.d = (const char *)nee + offsetof(NeeRec, dA); io.d_es = sizeof(NeeRec); io.d_cs = 4;
+            io.o = nee + WORD_OF(NeeRec, oA) * plane; io.o_es = 4; io.o_cs = plane;
+            io.d = nee + WORD_OF(NeeRec, dA) * plane; io.d_es = 4; io.d_cs = plane;
             io.tmax_const = 1 - 0.0001f;
-            io.prim = (char *)nee + offsetof(NeeRec, occA); io.prim_es = sizeof(NeeRec);
+            io.prim = (char *)nee + WORD_OF(NeeRec, occA) * plane; io.prim_es = 4;
             io.counter = fetch + 1;
             launch_ptrace(ctx, s, io, n_upper, true, false, K_SHADOW);
         }
@@ -647,11 +699,11 @@ static void enqueue_bounce(PtrContext *ctx, Lane &l, const PassParams &prm, cons
             TraceIO io;
             memset(&io, 0, sizeof(io));
             io.queue = q_mis; io.n_ptr = cnt + 3;
-            io.o = (const char *)nee + offsetof(NeeRec, oB); io.o_es = sizeof(NeeRec); io.o_cs = 4;
-            io.d = (const char *)nee + offsetof(NeeRec, dB); io.d_es = sizeof(NeeRec); io.d_cs = 4;
+            io.o = nee + WORD_OF(NeeRec, oB) * plane; io.o_es = 4; io.o_cs = plane;
+            io.d = nee + WORD_OF(NeeRec, dB) * plane; io.d_es = 4; io.d_cs = plane;
             io.tmax_const = FLT_MAX;
-            io.prim = (char *)nee + offsetof(NeeRec, hitB); io.prim_es = sizeof(NeeRec);
-            io.t = (char *)nee + offsetof(NeeRec, tB); io.t_es = sizeof(NeeRec);
+            io.prim = (char *)nee + WORD_OF(NeeRec, hitB) * plane; io.prim_es = 4;
+            io.t = (char *)nee + WORD_OF(NeeRec, tB) * plane; io.t_es = 4;
             io.counter = fetch + 2;
             launch_ptrace(ctx, s, io, n_upper, false, false, K_MIS);
         }
@@ -934,8 +986,8 @@ int ptr_film_init(PtrContext *ctx, int width, int height, uint64_t seed) {
             HIPCHK(hipMalloc((void **)&l.pipe.hprim, sizeof(int) * cap));
             HIPCHK(hipMalloc((void **)&l.pipe.hface, sizeof(int) * cap));
             HIPCHK(hipMalloc((void **)&l.pipe.ht, sizeof(float) * cap));
-            HIPCHK(hipMalloc((void **)&l.pipe.paths, sizeof(PathRec) * cap));
-            HIPCHK(hipMalloc((void **)&l.pipe.nee, sizeof(NeeRec) * cap));
+            HIPCHK(hipMalloc((void **)&l.pipe.paths, sizeof(PathRec) * cap)); /* PATH_WORDS planes */
+            HIPCHK(hipMalloc((void **)&l.pipe.nee, sizeof(NeeRec) * cap));     /* NEE_WORDS planes */
             for (int q = 0; q < 6; q++) HIPCHK(hipMalloc((void **)&l.queues[q], sizeof(int) * cap));
             HIPCHK(hipMalloc((void **)&l.counts, LANE_COUNTER_INTS * sizeof(int)));
             HIPCHK(hipHostMalloc((void **)&l.counts_host, 4 * MAX_ITERS * sizeof(int), hipHostMallocDefault));
