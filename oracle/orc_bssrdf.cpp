@@ -328,7 +328,8 @@ static V3 Sample_Sp(const Scene &sc, const SeparableBSSRDF &b, Float u1, const V
     std::vector<SurfaceInteraction> si(maxSi);
     int nFound = 0;
     SurfaceInteraction *ptr = &si[nFound];
-    while (true) {
+    /* the reference's loop is unbounded; oracle and product both stop a chain stuck on a degenerate hit after 4096 segments */
+    for (int step = 0; step < 4096; step++) {
         Ray ray = SpawnRayToPoint(base, pTarget);
         g_ctr.probe_rays++;
         bool hit = SceneIntersect(sc, ray, ptr);

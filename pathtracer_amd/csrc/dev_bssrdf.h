@@ -1,0 +1,375 @@
+/*
+ * dev_bssrdf.h — tabulated separable BSSRDF on the device (Subsurface / KdSubsurface materials).
+ * Reference: SeparableBSSRDF src/core/bssrdf.h:84-160 and bssrdf.cpp:383-581 (Sr, Pdf_Sr,
+ * Sample_Sr, Sample_Sp, Pdf_Sp, Sample_S), Catmull-Rom utilities bssrdf.cpp:32-191,328-357,
+ * SubsurfaceFromDiffuse :359-369, and the BSSRDF tail of the integrators (main.cpp:207-228,
+ * 320-342).  The profile table itself is built on the host at upload (ptr_tables.cpp).
+ *
+ * The probe segment of Sample_Sp is the one place on the path where a vertex issues an unknown
+ * number of scene queries before it can go on, so it is traversed in-kernel (traverse<> on the
+ * lane's own stack) instead of through the ray queues.  The reference keeps up to 256 surface
+ * interactions in a 39 KB per-thread array and picks one afterwards; here the chain is walked
+ * twice - once to count the hits on the probed primitive, once more up to the chosen one - which
+ * needs no per-lane storage and visits the same hits (the chain is deterministic).
+ */
+#pragma once
+#include "dev_nee.h"
+
+struct Bssrdf {
+    f3 po_p;
+    int po_prim;
+    f3 ns, ss, ts; /* frame at the point of entry (bssrdf.h:108-117) */
+    float eta;
+    f3 sigma_t, rho;
+    const DTable *t;
+};
+
+PD float comp3(const f3 &v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
+
+/* geometry.h:1091-1107 over a node array with pred nodes[i] <= x */
+PD int interval_leq(const float *nodes, int size, float x) {
+    int first = 0, len = size;
+    while (len > 0) {
+        int half = len >> 1, mid = first + half;
+        if (nodes[mid] <= x) { first = mid + 1; len -= half + 1; }
+        else len = half;
+    }
+    return clampi(first - 1, 0, size - 2);
+}
+
+/* CatmullRomWeights, bssrdf.cpp:32-67 */
+PD bool spline_weights(int size, const float *nodes, float x, int *offset, float &w0, float &w1, float &w2, float &w3) {
+    if (!(x >= nodes[0] && x <= nodes[size - 1])) return false;
+    int idx = interval_leq(nodes, size, x);
+    *offset = idx - 1;
+    float x0 = nodes[idx], x1 = nodes[idx + 1];
+    float t = (x - x0) / (x1 - x0), t2 = t * t, t3 = t2 * t;
+    w1 = 2 * t3 - 3 * t2 + 1;
+    w2 = -2 * t3 + 3 * t2;
+    if (idx > 0) {
+        float a = (t3 - 2 * t2 + t) * (x1 - x0) / (x1 - nodes[idx - 1]);
+        w0 = -a;
+        w2 += a;
+    } else {
+        float a = t3 - 2 * t2 + t;
+        w0 = 0;
+        w1 -= a;
+        w2 += a;
+    }
+    if (idx + 2 < size) {
+        float c = (t3 - t2) * (x1 - x0) / (nodes[idx + 2] - x0);
+        w1 -= c;
+        w3 = c;
+    } else {
+        float c = t3 - t2;
+        w1 -= c;
+        w2 += c;
+        w3 = 0;
+    }
+    return true;
+}
+
+/* one column of a (size1 x size2) table blended over 4 rows; rows with weight 0 are not read
+ * (the first / last row offset may lie outside the table) */
+struct RowBlend {
+    const float *base; /* array + offset * size2 */
+    int size2;
+    float w0, w1, w2, w3;
+    PD float at(const float *array_at_offset, int idx) const {
+        float v = 0;
+        if (w0 != 0) v += array_at_offset[idx] * w0;
+        if (w1 != 0) v += array_at_offset[size2 + idx] * w1;
+        if (w2 != 0) v += array_at_offset[2 * size2 + idx] * w2;
+        if (w3 != 0) v += array_at_offset[3 * size2 + idx] * w3;
+        return v;
+    }
+};
+
+/* SampleCatmullRom2D, bssrdf.cpp:69-139 */
+PD float spline_sample_2d(int size1, int size2, const float *nodes1, const float *nodes2, const float *values, const float *cdf, float alpha,
+                          float u) {
+    int offset;
+    RowBlend rb;
+    rb.size2 = size2;
+    if (!spline_weights(size1, nodes1, alpha, &offset, rb.w0, rb.w1, rb.w2, rb.w3)) return 0;
+    const float *cdf_o = cdf + (long)offset * size2, *val_o = values + (long)offset * size2;
+    float maximum = rb.at(cdf_o, size2 - 1);
+    u *= maximum;
+    int idx;
+    {
+        int first = 0, len = size2;
+        while (len > 0) {
+            int half = len >> 1, mid = first + half;
+            if (rb.at(cdf_o, mid) <= u) { first = mid + 1; len -= half + 1; }
+            else len = half;
+        }
+        idx = clampi(first - 1, 0, size2 - 2);
+    }
+    float f0 = rb.at(val_o, idx), f1 = rb.at(val_o, idx + 1);
+    float x0 = nodes2[idx], x1 = nodes2[idx + 1];
+    float width = x1 - x0;
+    float d0, d1;
+    u = (u - rb.at(cdf_o, idx)) / width;
+    if (idx > 0) d0 = width * (f1 - rb.at(val_o, idx - 1)) / (x1 - nodes2[idx - 1]);
+    else d0 = f1 - f0;
+    if (idx + 2 < size2) d1 = width * (rb.at(val_o, idx + 2) - f0) / (nodes2[idx + 2] - x0);
+    else d1 = f1 - f0;
+    float t;
+    if (f0 != f1) t = (f0 - sqrtf(fmaxr((float)0, f0 * f0 + 2 * u * (f1 - f0)))) / (f0 - f1);
+    else t = u / f0;
+    float a = 0, b = 1, Fhat, fhat;
+    for (int guard = 0; guard < 128; guard++) { /* the bracket halves whenever Newton leaves it: ends in ~25 rounds */
+        if (!(t >= a && t <= b)) t = 0.5f * (a + b);
+        Fhat = t * (f0 + t * (.5f * d0 + t * ((1.f / 3.f) * (-2 * d0 - d1) + f1 - f0 + t * (.25f * (d0 + d1) + .5f * (f0 - f1)))));
+        fhat = f0 + t * (d0 + t * (-2 * d0 - d1 + 3 * (f1 - f0) + t * (d0 + d1 + 2 * (f0 - f1))));
+        if (absr(Fhat - u) < 1e-6f || b - a < 1e-6f) break;
+        if (Fhat - u < 0) a = t;
+        else b = t;
+        t -= (Fhat - u) / fhat;
+    }
+    return x0 + width * t;
+}
+
+/* InvertCatmullRom, bssrdf.cpp:328-357 */
+PD float spline_invert(int n, const float *x, const float *values, float u) {
+    if (!(u > values[0])) return x[0];
+    else if (!(u < values[n - 1])) return x[n - 1];
+    int i = interval_leq(values, n, u);
+    float x0 = x[i], x1 = x[i + 1];
+    float f0 = values[i], f1 = values[i + 1];
+    float width = x1 - x0;
+    float d0, d1;
+    if (i > 0) d0 = width * (f1 - values[i - 1]) / (x1 - x[i - 1]);
+    else d0 = f1 - f0;
+    if (i + 2 < n) d1 = width * (values[i + 2] - f0) / (x[i + 2] - x0);
+    else d1 = f1 - f0;
+    float a = 0, b = 1, t = .5f;
+    float Fhat, fhat;
+    for (int guard = 0; guard < 128; guard++) {
+        if (!(t > a && t < b)) t = 0.5f * (a + b);
+        float t2 = t * t, t3 = t2 * t;
+        Fhat = (2 * t3 - 3 * t2 + 1) * f0 + (-2 * t3 + 3 * t2) * f1 + (t3 - 2 * t2 + t) * d0 + (t3 - t2) * d1;
+        fhat = (6 * t2 - 6 * t) * f0 + (-6 * t2 + 6 * t) * f1 + (3 * t2 - 4 * t + 1) * d0 + (3 * t2 - 2 * t) * d1;
+        if (absr(Fhat - u) < 1e-6f || b - a < 1e-6f) break;
+        if (Fhat - u < 0) a = t;
+        else b = t;
+        t -= (Fhat - u) / fhat;
+    }
+    return x0 + t * width;
+}
+
+/* the material's BSSRDF at a vertex: subsurface.cpp:60-73 / kdsubsurface.cpp:78-93 (coefficients,
+ * KdSubsurface inverts the diffuse reflectance first: SubsurfaceFromDiffuse) + bssrdf.cpp:726-735 */
+PD void bssrdf_make(const DScene &sc, const BssrdfParams &bp, const SI &po, const BSDF &frame, Bssrdf *b) {
+    const DTable *t = &sc.tables[bp.table];
+    f3 sa = bp.sigma_a, ss = bp.sigma_s;
+    if (bp.kd_mode) {
+        float r0 = spline_invert(t->nRho, t->rhoSamples, t->rhoEff, bp.kd.x);
+        float r1 = spline_invert(t->nRho, t->rhoSamples, t->rhoEff, bp.kd.y);
+        float r2 = spline_invert(t->nRho, t->rhoSamples, t->rhoEff, bp.kd.z);
+        ss = f3(r0 / bp.mfree.x, r1 / bp.mfree.y, r2 / bp.mfree.z);
+        sa = f3((1 - r0) / bp.mfree.x, (1 - r1) / bp.mfree.y, (1 - r2) / bp.mfree.z);
+    }
+    b->po_p = po.p;
+    b->po_prim = po.prim;
+    b->ns = frame.ns; b->ss = frame.ss; b->ts = frame.ts; /* same construction as the BSDF's frame (reflection.h:367-369) */
+    b->eta = bp.eta;
+    b->t = t;
+    b->sigma_t = sa + ss;
+    b->rho = f3(!is_zero(b->sigma_t.x) ? ss.x / b->sigma_t.x : 0.f, !is_zero(b->sigma_t.y) ? ss.y / b->sigma_t.y : 0.f,
+                !is_zero(b->sigma_t.z) ? ss.z / b->sigma_t.z : 0.f);
+}
+
+/* profile(rho row, radius column) blended with both sets of spline weights; skip = which products
+ * count as zero (Sr: IsZero(w_rho * w_radius); Pdf_Sr: IsZero of either) */
+PD float profile_blend(const DTable *t, int ro, int qo, const float *wr, const float *wq, bool product_rule, float *rhoEff) {
+    float sr = 0, re = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (!product_rule) {
+            if (is_zero(wr[i])) continue;
+            re += t->rhoEff[ro + i] * wr[i];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (product_rule) {
+                float weight = wr[i] * wq[j];
+                if (!is_zero(weight)) sr += weight * t->profile[(ro + i) * t->nRadius + qo + j];
+            } else {
+                if (is_zero(wq[j])) continue;
+                sr += t->profile[(ro + i) * t->nRadius + qo + j] * wr[i] * wq[j];
+            }
+        }
+    }
+    if (rhoEff) *rhoEff = re;
+    return sr;
+}
+
+/* TabulatedBSSRDF::Sr, bssrdf.cpp:383-411 */
+PD f3 bssrdf_sr(const Bssrdf &b, float r) {
+    const DTable *t = b.t;
+    float out[3] = {0, 0, 0};
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        float rOptical = r * comp3(b.sigma_t, ch);
+        int ro, qo;
+        float wr[4], wq[4];
+        if (!spline_weights(t->nRho, t->rhoSamples, comp3(b.rho, ch), &ro, wr[0], wr[1], wr[2], wr[3]) ||
+            !spline_weights(t->nRadius, t->radiusSamples, rOptical, &qo, wq[0], wq[1], wq[2], wq[3]))
+            continue;
+        float sr = profile_blend(t, ro, qo, wr, wq, true, nullptr);
+        if (!is_zero(rOptical)) sr /= 2 * kPi * rOptical;
+        out[ch] = sr;
+    }
+    f3 Sr(out[0], out[1], out[2]);
+    Sr *= b.sigma_t * b.sigma_t;
+    return clamp11(Sr);
+}
+/* Pdf_Sr, bssrdf.cpp:413-437 */
+PD float bssrdf_pdf_sr(const Bssrdf &b, int ch, float r) {
+    const DTable *t = b.t;
+    float st = comp3(b.sigma_t, ch);
+    float rOptical = r * st;
+    int ro, qo;
+    float wr[4], wq[4];
+    if (!spline_weights(t->nRho, t->rhoSamples, comp3(b.rho, ch), &ro, wr[0], wr[1], wr[2], wr[3]) ||
+        !spline_weights(t->nRadius, t->radiusSamples, rOptical, &qo, wq[0], wq[1], wq[2], wq[3]))
+        return 0.f;
+    float rhoEff = 0;
+    float sr = profile_blend(t, ro, qo, wr, wq, false, &rhoEff);
+    if (!is_zero(rOptical)) sr /= 2 * kPi * rOptical;
+    return fmaxr((float)0, sr * st * st / rhoEff);
+}
+/* Sample_Sr, bssrdf.cpp:439-445 */
+PD float bssrdf_sample_sr(const Bssrdf &b, int ch, float u) {
+    float st = comp3(b.sigma_t, ch);
+    if (is_zero(st)) return -1;
+    const DTable *t = b.t;
+    return spline_sample_2d(t->nRho, t->nRadius, t->rhoSamples, t->radiusSamples, t->profile, t->profileCDF, comp3(b.rho, ch), u) / st;
+}
+/* Pdf_Sp, bssrdf.cpp:562-581 */
+PD float bssrdf_pdf_sp(const Bssrdf &b, const f3 &pi_p, const f3 &pi_n) {
+    f3 d = b.po_p - pi_p;
+    f3 dLocal(dot(b.ss, d), dot(b.ts, d), dot(b.ns, d));
+    f3 nLocal(dot(b.ss, pi_n), dot(b.ts, pi_n), dot(b.ns, pi_n));
+    float rProj[3] = {sqrtf(dLocal.y * dLocal.y + dLocal.z * dLocal.z), sqrtf(dLocal.z * dLocal.z + dLocal.x * dLocal.x),
+                      sqrtf(dLocal.x * dLocal.x + dLocal.y * dLocal.y)};
+    float pdf = 0;
+    const float axisProb[3] = {.25f, .25f, .5f};
+    const float chProb = 1 / (float)3;
+#pragma unroll
+    for (int axis = 0; axis < 3; ++axis)
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) pdf += bssrdf_pdf_sr(b, ch, rProj[axis]) * absr(comp3(nLocal, axis)) * chProb * axisProb[axis];
+    return pdf;
+}
+
+#define PROBE_MAX_FOUND 256   /* bssrdf.cpp:506: SurfaceInteraction si[256] */
+#define PROBE_MAX_STEPS 4096  /* the reference's loop is unbounded; a chain stuck on a degenerate hit ends here */
+
+/* The probe chain of Sample_Sp (bssrdf.cpp:511-546): segments from the last hit towards pTarget
+ * (Interaction::SpawnRayTo(Point3f), interaction.cpp:12-16: direction = target - p, not offset).
+ * Returns how many hits lay on `prim`; with pick >= 0 stops at that hit and fills *out. */
+PD int bssrdf_probe_chain(const DScene &sc, const f3 &start, const f3 &pTarget, int prim, int pick, SI *out, unsigned *probes,
+                          const LaneStack &ls) {
+    f3 p = start, pErr(0.f), n(0.f);
+    int med_in = -1, med_out = -1;
+    int nFound = 0;
+    for (int step = 0; step < PROBE_MAX_STEPS; step++) {
+        f3 d = pTarget - p;
+        f3 o = offset_ray_origin(p, pErr, n, d);
+        int med = si_medium(n, med_in, med_out, d);
+        float tmax = 1 - kShadowEpsilon, b0, b1;
+        int hp = -1, hf = 0;
+        if (probes) (*probes)++;
+        bool hit = traverse<false, false>(sc, o, d, tmax, hp, hf, b0, b1, nullptr, ls);
+        if (is_black(d) || !hit) break;
+        SI si;
+        make_si(sc, hp, hf, o, d, tmax, med, &si);
+        p = si.p; pErr = si.pError; n = si.n; med_in = si.med_in; med_out = si.med_out;
+        if (hp == prim) {
+            if (nFound == pick) { *out = si; return nFound + 1; }
+            nFound++;
+            if (nFound > PROBE_MAX_FOUND - 1) break;
+        }
+    }
+    return nFound;
+}
+
+/* Sample_Sp, bssrdf.cpp:462-560 */
+PD f3 bssrdf_sample_sp(const DScene &sc, const Bssrdf &b, float u1, const f2 &u2, SI *pi, float *pdf, unsigned *probes, const LaneStack &ls) {
+    f3 vx, vy, vz;
+    *pdf = 0;
+    if (u1 < .5f) { vx = b.ss; vy = b.ts; vz = b.ns; u1 *= 2; }
+    else if (u1 < .75f) { vx = b.ts; vy = b.ns; vz = b.ss; u1 = (u1 - .5f) * 4; }
+    else { vx = b.ns; vy = b.ss; vz = b.ts; u1 = (u1 - .75f) * 4; }
+    int ch = clampi((int)(u1 * 3), 0, 2);
+    u1 = u1 * 3 - ch;
+    float r = bssrdf_sample_sr(b, ch, u2.x);
+    if (r < 0) return f3(0.f);
+    float phi = 2 * kPi * u2.y;
+    float rMax = bssrdf_sample_sr(b, ch, 0.999f);
+    if (r >= rMax) return f3(0.f);
+    float l = 2 * sqrtf(rMax * rMax - r * r);
+    f3 start = b.po_p + r * (vx * cosf(phi) + vy * sinf(phi)) - l * vz * 0.5f;
+    f3 pTarget = start + l * vz;
+    int nFound = bssrdf_probe_chain(sc, start, pTarget, b.po_prim, -1, pi, probes, ls);
+    if (nFound == 0) return f3(0.0f);
+    int selected = clampi((int)(u1 * nFound), 0, nFound - 1);
+    bssrdf_probe_chain(sc, start, pTarget, b.po_prim, selected, pi, nullptr, ls);
+    *pdf = bssrdf_pdf_sp(b, pi->p, pi->n) / nFound;
+    return bssrdf_sr(b, length(b.po_p - pi->p));
+}
+
+/* The BSSRDF tail of Li_PathSampled / Li_VolPath (main.cpp:207-228, 320-342) after the surface
+ * BSDF sampled a transmission: pick the exit point, account for direct light there (added to
+ * *L_extra: it follows the vertex's own direct-light term in L), sample the exit direction.
+ * Returns false if the path ends. */
+PD bool bssrdf_step(const DScene &sc, BSDF &bsdf, const BssrdfParams &bp, const SI &po, Rng &rng, bool handleMedium, bool walk, f3 *L_extra,
+                    f3 &beta, int &pflags, f3 &ro, f3 &rd, int &ray_medium, NeeCtr &nctr, unsigned *probes, const LaneStack &ls) {
+    Bssrdf b;
+    bssrdf_make(sc, bp, po, bsdf, &b);
+    SI pi;
+    float pdf = 0;
+    bsdf.n = 0;
+    float u1 = rng.next();
+    f2 u2 = rand2(rng);
+    f3 S = bssrdf_sample_sp(sc, b, u1, u2, &pi, &pdf, probes, ls);
+    if (!is_black(S)) { /* Sample_S, bssrdf.cpp:447-460: the exit vertex scatters through the Sw adapter lobe */
+        Lobe &lb = bsdf.l[bsdf.n++];
+        lobe_clear(lb);
+        lb.type = BSDF_REFLECTION | BSDF_DIFFUSE;
+        lb.impl = LB_BSSRDF_ADAPTER;
+        lb.bss_eta = b.eta;
+        pi.wo = pi.n;
+    }
+    if (is_black(S) || is_zero(pdf)) return false;
+    beta *= S / pdf;
+    u2 = rand2(rng);
+    f3 u3 = rand3(rng);
+    if (sc.n_lights >= 1) {
+        NeeRec r2;
+        int fl = build_nee(sc, ref_from_si(pi), &bsdf, 0, u2, u3, handleMedium, beta, false, NeeToStruct{&r2});
+        if (fl) {
+            if (walk) {
+                if (fl & NEE_A) nee_shadow<true>(sc, &r2, nctr, ls);
+                *L_extra = nee_mis_resolve<true>(sc, r2, nctr, ls);
+            } else {
+                if (fl & NEE_A) nee_shadow<false>(sc, &r2, nctr, ls);
+                *L_extra = nee_mis_resolve<false>(sc, r2, nctr, ls);
+            }
+        }
+    }
+    u2 = rand2(rng);
+    f3 wi;
+    int flags = 0;
+    f3 f = bsdf_sample_f(bsdf, pi.wo, &wi, u2, &pdf, BSDF_ALL, &flags);
+    if (is_black(f) || is_zero(pdf)) return false;
+    beta *= f * absdot(wi, pi.n) / pdf;
+    if (flags & BSDF_SPECULAR) pflags |= PFL_SPECULAR;
+    else pflags &= ~PFL_SPECULAR;
+    ro = offset_ray_origin(pi.p, pi.pError, pi.n, wi);
+    ray_medium = si_medium(pi.n, pi.med_in, pi.med_out, wi);
+    rd = wi;
+    return true;
+}

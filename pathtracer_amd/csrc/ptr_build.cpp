@@ -532,8 +532,6 @@ int ptr_flatten(const PtrFlatScene *fs, HostScene *hs, std::string *err) {
             for (int k = 0; k < 3; k++) pr.L[k] = pp.mat.textures[0].spec[k];
         } else {
             if (!pp.no_mat && pp.mat.type >= PTR_MAT_MATTE && pp.mat.type <= PTR_MAT_PLAYGROUND) {
-                if (pp.mat.type == PTR_MAT_SUBSURFACE || pp.mat.type == PTR_MAT_KDSUBSURFACE)
-                    return fail(err, PTR_ERR_LIMIT, "subsurface materials are not implemented on the device yet");
                 DMat m;
                 memset(&m, 0, sizeof(m));
                 m.type = pp.mat.type;
@@ -550,6 +548,21 @@ int ptr_flatten(const PtrFlatScene *fs, HostScene *hs, std::string *err) {
                     else { d.v[0] = t.spec[0]; d.v[1] = t.spec[1]; d.v[2] = t.spec[2]; }
                     if (t.type == 2 && (t.image < 0 || t.image >= fs->n_images)) return fail(err, PTR_ERR_INVALID, "texture image index out of range");
                     if (t.type < 0 || t.type > 2) { d.type = 0; }
+                }
+                if (pp.mat.type == PTR_MAT_SUBSURFACE || pp.mat.type == PTR_MAT_KDSUBSURFACE) {
+                    /* subsurface.cpp:15-16 (g = vals[2], eta = vals[1]) / kdsubsurface.cpp:33 (g = 0, eta = vals[0]);
+                     * the reference builds one table per material, equal inputs give equal tables: shared here */
+                    const float g = pp.mat.type == PTR_MAT_SUBSURFACE ? pp.mat.vals[2] : 0.f;
+                    const float eta = pp.mat.type == PTR_MAT_SUBSURFACE ? pp.mat.vals[1] : pp.mat.vals[0];
+                    for (size_t k = 0; k < hs->tables.size() && m.table < 0; k++)
+                        if (hs->tables[k].g == g && hs->tables[k].eta == eta) m.table = (int)k;
+                    if (m.table < 0) {
+                        m.table = (int)hs->tables.size();
+                        hs->tables.emplace_back();
+                        hs->tables.back().g = g;
+                        hs->tables.back().eta = eta;
+                        ptr_build_bssrdf_table(g, eta, &hs->tables.back());
+                    }
                 }
                 pr.material = (int)hs->mats.size();
                 hs->mats.push_back(m);

@@ -24,6 +24,11 @@ struct HostCloud {
     int n;
     float radius;
 };
+struct HostTable { /* BSSRDFTable, bssrdf.h:29-42 */
+    int n_rho, n_radius;
+    float g, eta; /* what it was built for */
+    std::vector<float> rho, radius, profile, rho_eff, profile_cdf;
+};
 struct HostScene {
     std::vector<Node64> nodes;
     std::vector<Item48> items;
@@ -34,6 +39,7 @@ struct HostScene {
     std::vector<HostImage> images;
     std::vector<HostMesh> meshes;
     std::vector<HostCloud> clouds;
+    std::vector<HostTable> tables;
     std::vector<float> tris;
     std::vector<int32_t> uvidx;
     std::vector<TopNode> top;   /* the reference's BVH over primitives */
@@ -47,4 +53,6 @@ struct HostScene {
 };
 
 /* returns PTR_OK or an error code with *err filled */
+/* photon-beam-diffusion profile table of a subsurface material (ptr_tables.cpp) */
+void ptr_build_bssrdf_table(float g, float eta, HostTable *t);
 int ptr_flatten(const PtrFlatScene *fs, HostScene *out, std::string *err);

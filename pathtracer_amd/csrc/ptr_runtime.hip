@@ -67,10 +67,13 @@ template <int W0, int W1, typename T> PD void soa_store(uint32_t *base, int cap,
 #define NEE_B_END WORD_OF(NeeRec, occA)
 #define NEE_RES_BEGIN WORD_OF(NeeRec, occA)
 #define NEE_RES_END (WORD_OF(NeeRec, tB) + 1)
+#define NEE_EXTRA_BEGIN WORD_OF(NeeRec, extra)
+#define NEE_EXTRA_END (WORD_OF(NeeRec, extra) + 3)
 PD void nee_load(const Pipe &pp, int slot, NeeRec *rec) { /* header, then only the halves in use */
     soa_load<0, 4>(pp.nee, pp.cap, slot, rec);
     if (rec->flags & NEE_A) soa_load<NEE_A_BEGIN, NEE_A_END>(pp.nee, pp.cap, slot, rec);
     if (rec->flags & NEE_B) soa_load<NEE_B_BEGIN, NEE_B_END>(pp.nee, pp.cap, slot, rec);
+    if (rec->flags & NEE_EXTRA) soa_load<NEE_EXTRA_BEGIN, NEE_EXTRA_END>(pp.nee, pp.cap, slot, rec);
 }
 
 __device__ __forceinline__ unsigned wave_sum(unsigned v) {
@@ -234,8 +237,19 @@ __global__ void __launch_bounds__(TPB) k_bin_scatter(DScene sc, Pipe pp, const i
     GRID_STRIDE_END
 }
 
-__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(SHADE_WAVES, SHADE_WAVES))) k_shade(DScene sc, Pipe pp, PassParams prm, const int *n_ptr, int n_host, const int *queue,
-                                               int *q_next, int *q_nee, int *q_shadow, int *q_mis, int *counts, unsigned long long *ctrs) {
+/* SSS = true (scenes with a subsurface material): the BSSRDF tail of a vertex is traversed in
+ * place, see dev_bssrdf.h; its occupancy is whatever the compiler can give it. */
+template <bool SSS>
+__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(SSS ? 1 : SHADE_WAVES, SSS ? 1 : SHADE_WAVES)))
+k_shade(DScene sc, Pipe pp, PassParams prm, const int *n_ptr, int n_host, const int *queue, int *q_next, int *q_nee, int *q_shadow, int *q_mis,
+        int *counts, int walk, unsigned long long *ctrs) {
+    __shared__ int s_stack[SSS ? LDS_STACK * TRACE_TPB : 1];
+    LaneStack ls;
+    ls.lds = &s_stack[SSS ? threadIdx.x : 0];
+    NeeCtr nctr;
+    nctr.shadow = nctr.mis = nctr.zero = 0;
+    unsigned probes = 0;
+    const SssCtx sss = {&ls, &nctr, &probes, walk != 0};
     VertexCtr ctr;
     ctr.total = ctr.miss = ctr.surf = ctr.med = ctr.light = ctr.zero = 0;
     GRID_STRIDE_BEGIN(n_ptr, n_host)
@@ -255,12 +269,18 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(SHADE_
         rng.dim = (uint32_t)ps.dim;
         f3 L = ld3(ps.L), beta = ld3(ps.beta);
         int med = ps.medium, bounces = ps.bounces, pflags = ps.flags;
-        VertexOut vo = shade_vertex(sc, prm.integrator, rng, ro, rd, med, pp.hprim[slot], pp.hface[slot], pp.ht[slot], L, beta, bounces,
-                                    pflags, rec, ctr);
+        VertexOut vo = shade_vertex<SSS>(sc, prm.integrator, rng, ro, rd, med, pp.hprim[slot], pp.hface[slot], pp.ht[slot], L, beta, bounces,
+                                         pflags, rec, ctr, &sss);
         alive = vo.alive;
         want_nee = vo.want_nee;
         want_shadow = want_nee && (vo.nee_flags & NEE_A);
         want_mis = want_nee && (vo.nee_flags & NEE_B);
+        if (SSS && vo.has_extra) {
+            if (want_nee) { /* keeps its place in L: after this vertex's own direct-light term */
+                rec.puti(NEE_W(flags), vo.nee_flags | NEE_EXTRA);
+                rec.put3(NEE_W(extra), vo.L_extra);
+            } else L += vo.L_extra;
+        }
         st3(ps.L, L);
         st3(ps.beta, beta);
         ps.medium = med;
@@ -284,6 +304,11 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(SHADE_
     ctr_flush(ctrs, C_MED, ctr.med);
     ctr_flush(ctrs, C_LIGHT, ctr.light);
     ctr_flush(ctrs, C_ZERO, ctr.zero);
+    if (SSS) {
+        ctr_flush(ctrs, C_SHADOW, nctr.shadow);
+        ctr_flush(ctrs, C_MIS, nctr.mis);
+        ctr_flush(ctrs, C_PROBE, probes);
+    }
 }
 
 /* direct-light stages with the walks of VisibilityTester::Tr / IntersectTr (scenes with medium
@@ -324,6 +349,7 @@ __global__ void __launch_bounds__(TPB) k_mis_walk(DScene sc, Pipe pp, const int 
         soa_load<0, 3>(pp.paths, pp.cap, slot, &ps);
         f3 L = ld3(ps.L);
         L += Ld;
+        if (rec.flags & NEE_EXTRA) L += ld3(rec.extra);
         st3(ps.L, L);
         soa_store<0, 3>(pp.paths, pp.cap, slot, &ps);
     }
@@ -348,6 +374,7 @@ __global__ void __launch_bounds__(TPB) k_nee_resolve(DScene sc, Pipe pp, const i
         soa_load<0, 3>(pp.paths, pp.cap, slot, &ps);
         f3 L = ld3(ps.L);
         L += Ld;
+        if (rec.flags & NEE_EXTRA) L += ld3(rec.extra);
         st3(ps.L, L);
         soa_store<0, 3>(pp.paths, pp.cap, slot, &ps);
     }
@@ -362,6 +389,7 @@ __global__ void __launch_bounds__(TPB) k_nee_resolve(DScene sc, Pipe pp, const i
  * wavefront stages have thinned the pass to a few per cent of its paths: from there on a bounce
  * is worth ~1e4 rays but would still cost three launches that each last as long as their longest
  * ray.  Same device functions, same order of operations per path as the staged kernels. */
+template <bool SSS>
 __global__ void __launch_bounds__(TPB) k_finish(DScene sc, Pipe pp, PassParams prm, const int *n_ptr, int n_host, const int *queue, int walk,
                                                 unsigned long long *ctrs) {
     __shared__ int s_stack[LDS_STACK * TRACE_TPB];
@@ -371,6 +399,8 @@ __global__ void __launch_bounds__(TPB) k_finish(DScene sc, Pipe pp, PassParams p
     ctr.total = ctr.miss = ctr.surf = ctr.med = ctr.light = ctr.zero = 0;
     NeeCtr nctr;
     nctr.shadow = nctr.mis = nctr.zero = 0;
+    unsigned probes = 0;
+    const SssCtx sss = {&ls, &nctr, &probes, walk != 0};
     GRID_STRIDE_BEGIN(n_ptr, n_host)
     if (i < n) {
         const int slot = queue ? queue[i] : i;
@@ -389,7 +419,7 @@ __global__ void __launch_bounds__(TPB) k_finish(DScene sc, Pipe pp, PassParams p
             float tmax = kInfinity, b0 = 0, b1 = 0;
             int hp = -1, hf = -1;
             bool hit = traverse<false, false>(sc, ro, rd, tmax, hp, hf, b0, b1, nullptr, ls);
-            VertexOut vo = shade_vertex(sc, prm.integrator, rng, ro, rd, med, hit ? hp : -1, hit ? hf : -1, tmax, L, beta, bounces, pflags, NeeToStruct{rec}, ctr);
+            VertexOut vo = shade_vertex<SSS>(sc, prm.integrator, rng, ro, rd, med, hit ? hp : -1, hit ? hf : -1, tmax, L, beta, bounces, pflags, NeeToStruct{rec}, ctr, &sss);
             if (vo.want_nee) {
                 f3 Ld;
                 if (walk) {
@@ -401,6 +431,7 @@ __global__ void __launch_bounds__(TPB) k_finish(DScene sc, Pipe pp, PassParams p
                 }
                 L += Ld;
             }
+            if (SSS && vo.has_extra) L += vo.L_extra;
             if (!vo.alive) break;
         }
         st3(ps.L, L);
@@ -420,6 +451,7 @@ __global__ void __launch_bounds__(TPB) k_finish(DScene sc, Pipe pp, PassParams p
     ctr_flush(ctrs, C_ZERO, ctr.zero + nctr.zero);
     ctr_flush(ctrs, C_SHADOW, nctr.shadow);
     ctr_flush(ctrs, C_MIS, nctr.mis);
+    if (SSS) ctr_flush(ctrs, C_PROBE, probes);
 }
 
 /* Render()'s accumulation (main.cpp:449-455): we += weight * L per sample, in sample order */
@@ -490,6 +522,7 @@ struct PtrContext {
     DScene sc;
     bool has_scene = false, has_camera = false, has_film = false;
     bool scene_has_media = false, scene_all_opaque = false, scene_passthrough = false;
+    bool scene_has_sss = false; /* some material carries a BSSRDF: k_shade<true> / k_finish<true> */
     DCamera cam;
     int64_t bvh_bytes = 0;
     /* film */
@@ -666,8 +699,13 @@ static void enqueue_bounce(PtrContext *ctx, Lane &l, const PassParams &prm, cons
     }
     {
         ProfScope ps(ctx, s, K_SHADE, (uint64_t)(n_ptr ? 0 : n_host));
-        hipLaunchKernelGGL(k_shade, dim3(stride_blocks), dim3(TPB), 0, s, ctx->sc, l.pipe, prm, n_ptr, n_host, q_shade, q_next, q_nee, q_shadow, q_mis,
-                           cnt, ctx->ctrs);
+        const int walk_i = prm.integrator == PTR_LI_VOLPATH && !ctx->scene_all_opaque ? 1 : 0;
+        if (ctx->scene_has_sss)
+            hipLaunchKernelGGL(k_shade<true>, dim3(stride_blocks), dim3(TPB), 0, s, ctx->sc, l.pipe, prm, n_ptr, n_host, q_shade, q_next, q_nee, q_shadow,
+                               q_mis, cnt, walk_i, ctx->ctrs);
+        else
+            hipLaunchKernelGGL(k_shade<false>, dim3(stride_blocks), dim3(TPB), 0, s, ctx->sc, l.pipe, prm, n_ptr, n_host, q_shade, q_next, q_nee, q_shadow,
+                               q_mis, cnt, walk_i, ctx->ctrs);
     }
     /* the walks of VisibilityTester::Tr / IntersectTr can only go past their first hit under
      * Li_VolPath and only if some primitive has no material (medium boundary, emitter) */
@@ -766,8 +804,12 @@ static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int ste
         const bool walk = integrator == PTR_LI_VOLPATH && !ctx->scene_all_opaque;
         int upper = slots >> (staged < 6 ? staged : 6);
         ProfScope ps(ctx, s, K_FINISH, 0);
-        hipLaunchKernelGGL(k_finish, dim3(clampu(nblocks(upper), 32, 2048)), dim3(TPB), 0, s, ctx->sc, l.pipe, prm,
-                           (const int *)(l.counts + 4 * (staged - 1)), 0, q_cur, walk ? 1 : 0, ctx->ctrs);
+        if (ctx->scene_has_sss)
+            hipLaunchKernelGGL(k_finish<true>, dim3(clampu(nblocks(upper), 32, 2048)), dim3(TPB), 0, s, ctx->sc, l.pipe, prm,
+                               (const int *)(l.counts + 4 * (staged - 1)), 0, q_cur, walk ? 1 : 0, ctx->ctrs);
+        else
+            hipLaunchKernelGGL(k_finish<false>, dim3(clampu(nblocks(upper), 32, 2048)), dim3(TPB), 0, s, ctx->sc, l.pipe, prm,
+                               (const int *)(l.counts + 4 * (staged - 1)), 0, q_cur, walk ? 1 : 0, ctx->ctrs);
     }
     l.staged_used = staged;
     l.slots_used = slots;
@@ -917,7 +959,18 @@ int ptr_scene_upload(PtrContext *ctx, const PtrFlatScene *scene) {
         if ((rc = upload(ctx, hs.clouds[i].pos.data(), hs.clouds[i].pos.size(), &dcloud[i].pos))) return rc;
     }
     if ((rc = upload(ctx, dcloud.data(), dcloud.size(), &sc.clouds))) return rc;
-    sc.tables = nullptr;
+    std::vector<DTable> dtab(hs.tables.size());
+    for (size_t i = 0; i < hs.tables.size(); i++) {
+        const HostTable &t = hs.tables[i];
+        dtab[i].nRho = t.n_rho;
+        dtab[i].nRadius = t.n_radius;
+        if ((rc = upload(ctx, t.rho.data(), t.rho.size(), &dtab[i].rhoSamples))) return rc;
+        if ((rc = upload(ctx, t.radius.data(), t.radius.size(), &dtab[i].radiusSamples))) return rc;
+        if ((rc = upload(ctx, t.profile.data(), t.profile.size(), &dtab[i].profile))) return rc;
+        if ((rc = upload(ctx, t.rho_eff.data(), t.rho_eff.size(), &dtab[i].rhoEff))) return rc;
+        if ((rc = upload(ctx, t.profile_cdf.data(), t.profile_cdf.size(), &dtab[i].profileCDF))) return rc;
+    }
+    if ((rc = upload(ctx, dtab.data(), dtab.size(), &sc.tables))) return rc;
     sc.env_marg_int = hs.env_marg_int;
     sc.env_w = hs.env_w; sc.env_h = hs.env_h; sc.env_nu = hs.env_nu; sc.env_nv = hs.env_nv;
     sc.n_prims = (int)hs.prims.size();
@@ -930,6 +983,7 @@ int ptr_scene_upload(PtrContext *ctx, const PtrFlatScene *scene) {
     ctx->sc = sc;
     ctx->bvh_bytes = (int64_t)(hs.nodes.size() * sizeof(Node64) + hs.items.size() * sizeof(Item48));
     ctx->scene_has_media = hs.has_media;
+    ctx->scene_has_sss = !hs.tables.empty();
     ctx->scene_all_opaque = true;
     ctx->scene_passthrough = false;
     for (const DPrim &pr : hs.prims) {

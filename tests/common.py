@@ -17,6 +17,8 @@ SCENES = {
     "zoo_sky_fog": ("zoo", 0, 3),
     "volcaustic": ("volcaustic", 0, 0),
     "fluid": ("fluid", 3000, 0),
+    "subsurface": ("subsurface", 0, 0),
+    "subsurface_knot": ("subsurface", 8, 0),
 }
 INTEGRATORS = {"direct": pa.LI_DIRECT, "path": pa.LI_PATH, "pathsampled": pa.LI_PATHSAMPLED, "volpath": pa.LI_VOLPATH}
 

@@ -196,10 +196,6 @@ def test_errors(cuda):
             r.film_init(0, 10)
         with pytest.raises(pa.PtrError):
             r.shard(2, 2)
-        sc = pa.BuiltScene("subsurface", W, H, 8, 0)
-        with pytest.raises(pa.PtrError) as e:
-            r.upload(sc)
-        assert e.value.code == pa.capi.PTR_ERR_LIMIT
 
 
 def test_film_tensor_views_for_the_all_reduce(scenes):
