@@ -193,12 +193,47 @@ PD float sdf_box(const f3 &p, const f3 &b) { /* :78-81 */
     f3 d = abs3(p) - b;
     return fminr(fmaxr(d.x, fmaxr(d.y, d.z)), 0.0f) + length(f3(fmaxr(d.x, 0.f), fmaxr(d.y, 0.f), fmaxr(d.z, 0.f)));
 }
-PD float proc_map(const DPrim &pr, const f3 &p, int *shapeId) {
+/* SDF::Triangle (procedural.cpp:112-130) against a record whose point-independent parts (edges,
+ * normal, the three double-precision cross products, squared lengths) were made on the host with the
+ * reference's arithmetic (ptr_toys.cpp) */
+PD float sdf_sign(float x) { /* procedural.cpp:14-18 */
+    if (is_zero(x)) return 0;
+    return x > 0 ? 1.f : -1.f;
+}
+PD float sdf_toy_triangle(const DToyTri &t, const f3 &p) {
+    f3 pa = p - f3(t.a[0], t.a[1], t.a[2]), pb = p - f3(t.b[0], t.b[1], t.b[2]), pc = p - f3(t.c[0], t.c[1], t.c[2]);
+    f3 ba(t.ba[0], t.ba[1], t.ba[2]), cb(t.cb[0], t.cb[1], t.cb[2]), ac(t.ac[0], t.ac[1], t.ac[2]);
+    float ss = sdf_sign(dot(f3(t.e0[0], t.e0[1], t.e0[2]), pa)) + sdf_sign(dot(f3(t.e1[0], t.e1[1], t.e1[2]), pb)) +
+               sdf_sign(dot(f3(t.e2[0], t.e2[1], t.e2[2]), pc));
+    if (ss < 2) {
+        float a2 = length2(ba * clampr(dot(ba, pa) / t.d2ba, 0.f, 1.f) - pa);
+        float b2 = length2(cb * clampr(dot(cb, pb) / t.d2cb, 0.f, 1.f) - pb);
+        float c2 = length2(ac * clampr(dot(ac, pc) / t.d2ac, 0.f, 1.f) - pc);
+        return sqrtf(fminr(a2, fminr(b2, c2)));
+    }
+    float dn = dot(f3(t.nor[0], t.nor[1], t.nor[2]), pa);
+    return sqrtf(dn * dn / t.d2nor);
+}
+PD float proc_map(const DScene &sc, const DPrim &pr, const f3 &p, int *shapeId) {
     if (pr.type == SH_SPHERE_PROC) return length(p) - pr.p[0];
     if (pr.type == SH_BOX_PROC) return sdf_box(p, f3(pr.p[0], pr.p[1], pr.p[2]) * 0.5f);
+    if (pr.toy_id >= 0 && pr.toy_id <= 3) {
+        /* origami toys, procedural.cpp:402-574: mirrored in z (the boat, id 0, also in x); the nearest
+         * triangle's id becomes the shape id (first one on ties), the dragon (id 1) always reports 5 */
+        f3 q(pr.toy_id == 0 ? absr(p.x) : p.x, p.y, absr(p.z));
+        float best = kInfinity;
+        int id = -1;
+        for (int i = 0; i < pr.geom; i++) {
+            const DToyTri &t = sc.toy_tris[pr.root + i];
+            float d = sdf_toy_triangle(t, q);
+            if (best > d) { best = d; id = (int)t.id; }
+        }
+        *shapeId = pr.toy_id == 1 ? 5 : id;
+        return best;
+    }
+    if (pr.toy_id != 4) return 0; /* "Unknown component id": Map returns false (:389-394) */
     /* SH_TOY id 4 "Terrain" (procedural.cpp:380-400): box over the component's extents */
     f3 len(absr(pr.p[3] - pr.p[0]), absr(pr.p[4] - pr.p[1]), absr(pr.p[5] - pr.p[2]));
-    (void)shapeId;
     return sdf_box(p, len * 0.5f);
 }
 PD void proc_local_bounds(const DPrim &pr, float *bmin, float *bmax) {
@@ -216,7 +251,7 @@ PD bool inside_box(const f3 &p, const float *bmin, const float *bmax) {
     return p.x >= bmin[0] && p.x <= bmax[0] && p.y >= bmin[1] && p.y <= bmax[1] && p.z >= bmin[2] && p.z <= bmax[2];
 }
 /* :187-227.  tHit is the distance along the NORMALISED direction (sic, :246). */
-PD bool proc_hit_t(const DPrim &pr, const f3 &ro, const f3 &rd, float rtmax, float *tHit, int *shapeId) {
+PD bool proc_hit_t(const DScene &sc, const DPrim &pr, const f3 &ro, const f3 &rd, float rtmax, float *tHit, int *shapeId) {
     f3 un = normalize(rd);
     f3 o, d;
     xf_ray_err(pr.w2o, ro, un, &o, &d);
@@ -234,7 +269,7 @@ PD bool proc_hit_t(const DPrim &pr, const f3 &ro, const f3 &rd, float rtmax, flo
     bool hit = false;
     for (int i = 0; i < 256 && t < tMax; i++) {
         f3 p = o + d * t;
-        float dd = proc_map(pr, p, &id);
+        float dd = proc_map(sc, pr, p, &id);
         if ((double)absr(dd) < (0.001 * t)) { hit = true; break; }
         t += dd;
         if (!inside_box(o + d * t, bmin, bmax)) break;
@@ -245,7 +280,7 @@ PD bool proc_hit_t(const DPrim &pr, const f3 &ro, const f3 &rd, float rtmax, flo
 
 /* Shape::Intersect of an analytic primitive: hit distance only (the interaction is rebuilt by
  * make_si for the one hit that survives) */
-PD bool shape_hit_t(const DPrim &pr, const f3 &ro, const f3 &rd, float tmax, float *tHit, int *face) {
+PD bool shape_hit_t(const DScene &sc, const DPrim &pr, const f3 &ro, const f3 &rd, float tmax, float *tHit, int *face) {
     *face = 0;
     switch (pr.type) {
     case SH_SPHERE: {
@@ -255,7 +290,7 @@ PD bool shape_hit_t(const DPrim &pr, const f3 &ro, const f3 &rd, float tmax, flo
     }
     case SH_RECT: return rect_hit_t(pr, ro, rd, tmax, tHit);
     case SH_DISK: return disk_hit_t(pr, ro, rd, tmax, tHit);
-    case SH_SPHERE_PROC: case SH_BOX_PROC: case SH_TOY: return proc_hit_t(pr, ro, rd, tmax, tHit, face);
+    case SH_SPHERE_PROC: case SH_BOX_PROC: case SH_TOY: return proc_hit_t(sc, pr, ro, rd, tmax, tHit, face);
     default: return false;
     }
 }
@@ -371,7 +406,7 @@ PD bool prim_closest(const DScene &sc, int p, const f3 &ro, const f3 &rd, const 
     float t;
     int face;
     if (COUNT) st->items += 1;
-    if (shape_hit_t(pr, ro, rd, tmax, &t, &face)) {
+    if (shape_hit_t(sc, pr, ro, rd, tmax, &t, &face)) {
         tmax = t; hprim = p; hface = face; hb0 = 0; hb1 = 0;
         return true;
     }
@@ -473,16 +508,16 @@ PD void sphere_si(const DPrim &pr, const float *o2w, const float *w2o, const f3 
 }
 
 /* procedural.cpp:145-185,228-247,263-352 */
-PD f3 proc_derivative_normal(const DPrim &pr, const f3 &p) {
+PD f3 proc_derivative_normal(const DScene &sc, const DPrim &pr, const f3 &p) {
     bool found = false;
     float scale = 0.001;
     f3 n;
     int it = 0, id;
     while (!found) {
         float e = scale * length(p);
-        float x = proc_map(pr, f3(p.x + e, p.y, p.z), &id) - proc_map(pr, f3(p.x - e, p.y, p.z), &id);
-        float y = proc_map(pr, f3(p.x, p.y + e, p.z), &id) - proc_map(pr, f3(p.x, p.y - e, p.z), &id);
-        float z = proc_map(pr, f3(p.x, p.y, p.z + e), &id) - proc_map(pr, f3(p.x, p.y, p.z - e), &id);
+        float x = proc_map(sc, pr, f3(p.x + e, p.y, p.z), &id) - proc_map(sc, pr, f3(p.x - e, p.y, p.z), &id);
+        float y = proc_map(sc, pr, f3(p.x, p.y + e, p.z), &id) - proc_map(sc, pr, f3(p.x, p.y - e, p.z), &id);
+        float z = proc_map(sc, pr, f3(p.x, p.y, p.z + e), &id) - proc_map(sc, pr, f3(p.x, p.y, p.z - e), &id);
         n = f3(x, y, z);
         found = !is_zero(length(n));
         if (!found) {
@@ -492,7 +527,7 @@ PD f3 proc_derivative_normal(const DPrim &pr, const f3 &p) {
     }
     return normalize(n);
 }
-PD void proc_si(const DPrim &pr, const f3 &ro, const f3 &rd, float t, int face, SI *si) {
+PD void proc_si(const DScene &sc, const DPrim &pr, const f3 &ro, const f3 &rd, float t, int face, SI *si) {
     f3 un = normalize(rd);
     f3 o, d;
     xf_ray_err(pr.w2o, ro, un, &o, &d);
@@ -541,7 +576,7 @@ PD void proc_si(const DPrim &pr, const f3 &ro, const f3 &rd, float t, int face, 
         uv = f2(u, v);
         refined = true;
     }
-    if (!refined) n = proc_derivative_normal(pr, pHit);
+    if (!refined) n = proc_derivative_normal(sc, pr, pHit);
     f3 dpdu, dpdv;
     coordinate_system(n, &dpdu, &dpdv);
     si_from_object(pr, pr.o2w, pr.w2o, pHit, uv, -d, dpdu, dpdv, face, si);
@@ -647,7 +682,7 @@ PD void make_si(const DScene &sc, int prim, int face, const f3 &ro, const f3 &rd
         si_from_object(pr, pr.o2w, pr.w2o, pHit, f2(u, v), -d, dpdu, dpdv, 0, si);
     } break;
     case SH_MESH: tri_si(sc, pr, ro, rd, face, si); break;
-    default: proc_si(pr, ro, rd, t, face, si); break;
+    default: proc_si(sc, pr, ro, rd, t, face, si); break;
     }
     si->prim = prim;
     if (pr.med_inside != pr.med_outside) { si->med_in = pr.med_inside; si->med_out = pr.med_outside; }

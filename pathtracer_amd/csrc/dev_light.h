@@ -217,7 +217,7 @@ PD float shape_pdf_generic(const DScene &sc, int prim, const Ref &ref, const f3 
     f3 ro = spawn_origin(ref, wi);
     float t;
     int face;
-    if (!shape_hit_t(sc.prims[prim], ro, wi, kInfinity, &t, &face)) return 0; /* Shape::Pdf, sphere.cpp:3-14 */
+    if (!shape_hit_t(sc, sc.prims[prim], ro, wi, kInfinity, &t, &face)) return 0; /* Shape::Pdf, sphere.cpp:3-14 */
     SI li;
     make_si(sc, prim, face, ro, wi, t, -1, &li);
     float f = (absdot(li.n, -wi) * sc.prims[prim].area);

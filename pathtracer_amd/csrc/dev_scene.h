@@ -90,6 +90,15 @@ struct DCloud {
     int32_t n;
     float radius;
 };
+/* One triangle of an origami signed-distance toy (procedural.cpp:402-574) with everything
+ * SDF::Triangle derives from its corners alone, precomputed on the host (ptr_toys.cpp): 144 B */
+struct DToyTri {
+    float a[3], b[3], c[3];
+    float ba[3], cb[3], ac[3], nor[3];
+    float e0[3], e1[3], e2[3]; /* Cross(ba, nor), Cross(cb, nor), Cross(ac, nor) */
+    float d2ba, d2cb, d2ac, d2nor;
+    float id, pad;
+};
 struct DTable { /* BSSRDFTable, bssrdf.h:29-42 (100 x 64) */
     const float *rhoSamples, *radiusSamples, *profile, *rhoEff, *profileCDF;
     int32_t nRho, nRadius;
@@ -106,6 +115,7 @@ struct DScene {
     const DMesh *meshes;
     const DCloud *clouds;
     const DTable *tables;
+    const DToyTri *toy_tris; /* origami toys: DPrim::root = first record, DPrim::geom = count */
     const float *tris;     /* 9 floats / triangle, original order, world space */
     const int32_t *uvidx;  /* 3 ints / triangle */
     const TopNode *top;    /* the reference's BVH over primitives, root = 0 */

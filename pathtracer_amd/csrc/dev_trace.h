@@ -182,7 +182,7 @@ PD void persistent_trace(const DScene &sc, const TraceIO &io, int *lds, unsigned
                         float t;
                         int face;
                         if (COUNT) ri += 1;
-                        if (shape_hit_t(pr, ro, rd, tmax, &t, &face)) {
+                        if (shape_hit_t(sc, pr, ro, rd, tmax, &t, &face)) {
                             tmax = t; hp = p; hf = face; hb0 = 0; hb1 = 0; hit = true;
                             if (ANY) { PT_FINISH(); break; }
                         }

@@ -476,7 +476,12 @@ int ptr_flatten(const PtrFlatScene *fs, HostScene *hs, std::string *err) {
             for (int k = 0; k < 6; k++) pr.p[k] = pp.params[k];
             for (int k = 0; k < 3; k++) { lmin[k] = pp.params[k]; lmax[k] = pp.params[3 + k]; }
             pr.toy_id = pp.geom;
-            if (pp.geom != 4) return fail(err, PTR_ERR_LIMIT, "procedural toy ids 0-3 (origami) are not implemented on the device yet");
+            if (pp.geom >= 0 && pp.geom <= 3) { /* origami: ProceduralComponent::Map's half extents, procedural.cpp:381-382 */
+                float half[3];
+                for (int k = 0; k < 3; k++) half[k] = fabsf(pp.params[3 + k] - pp.params[k]) * 0.5f;
+                pr.root = (int)hs->toy_tris.size();
+                pr.geom = ptr_build_toy(pp.geom, half, &hs->toy_tris);
+            }
             reverse = false;
             pr.area = 1;
             break;
@@ -510,7 +515,7 @@ int ptr_flatten(const PtrFlatScene *fs, HostScene *hs, std::string *err) {
 
         Box pb;
         pb.reset();
-        pr.root = BVH_NO_CHILD;
+        if (pp.shape_type != PTR_SHAPE_COMPONENT_PROCEDURAL) pr.root = BVH_NO_CHILD; /* toys: first DToyTri record, set above */
         if (pp.shape_type == PTR_SHAPE_MESH) {
             if (hs->meshes[pp.geom].n_tris == 0) continue; /* an empty mesh has no bounds; the reference would crash */
             pb = mesh_box[pp.geom];
@@ -621,6 +626,14 @@ int ptr_flatten(const PtrFlatScene *fs, HostScene *hs, std::string *err) {
         float dx = c[0] - world.mx[0], dy = c[1] - world.mx[1], dz = c[2] - world.mx[2];
         l.worldRadius = inside ? sqrtf(dx * dx + dy * dy + dz * dz) : 0;
         hs->lights.push_back(l);
+    }
+    /* what the kernels index without checks must be in range before anything is uploaded */
+    for (const DPrim &pr : hs->prims) {
+        if (pr.type == SH_TOY && pr.toy_id >= 0 && pr.toy_id <= 3 &&
+            (pr.root < 0 || pr.geom < 0 || (size_t)pr.root + (size_t)pr.geom > hs->toy_tris.size()))
+            return fail(err, PTR_ERR_STATE, "internal: toy triangle range out of bounds");
+        if (pr.material >= 0 && hs->mats[pr.material].table >= (int)hs->tables.size())
+            return fail(err, PTR_ERR_STATE, "internal: BSSRDF table index out of bounds");
     }
     if (hs->lights.size() > PTR_MAX_LIGHTS) return fail(err, PTR_ERR_LIMIT, "more than 256 lights (Aggregator::lightList[256])");
 

@@ -40,6 +40,7 @@ struct HostScene {
     std::vector<HostMesh> meshes;
     std::vector<HostCloud> clouds;
     std::vector<HostTable> tables;
+    std::vector<DToyTri> toy_tris;
     std::vector<float> tris;
     std::vector<int32_t> uvidx;
     std::vector<TopNode> top;   /* the reference's BVH over primitives */
@@ -55,4 +56,6 @@ struct HostScene {
 /* returns PTR_OK or an error code with *err filled */
 /* photon-beam-diffusion profile table of a subsurface material (ptr_tables.cpp) */
 void ptr_build_bssrdf_table(float g, float eta, HostTable *t);
+/* triangle records of an origami toy (ptr_toys.cpp); returns how many were appended */
+int ptr_build_toy(int id, const float *half, std::vector<DToyTri> *out);
 int ptr_flatten(const PtrFlatScene *fs, HostScene *out, std::string *err);

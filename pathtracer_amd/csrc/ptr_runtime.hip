@@ -9,10 +9,8 @@
  * with compacted queues of live paths between the stages, so the traversal kernel runs with full
  * wavefronts and small per-lane state.
  */
-#include "dev_path.h"
-#include "dev_trace.h"
+#include "rt_common.h"
 #include "ptr_host.h"
-#include <hip/hip_runtime.h>
 #include <cfloat>
 #include <cstddef>
 #include <cstdio>
@@ -20,86 +18,6 @@
 #include <cstring>
 #include <string>
 #include <vector>
-
-/* ------------------------------------------------------------------------------------------
- * device helpers
- * ---------------------------------------------------------------------------------------- */
-#define TPB 256
-#ifndef PT_WAVES
-#define PT_WAVES 5 /* wavefronts per SIMD the persistent tracer is compiled for */
-#endif
-
-struct Pipe {
-    float *ro, *rd;      /* 3 planes of cap floats each */
-    int *hprim, *hface;
-    float *ht;
-    uint32_t *paths; /* PathRec as PATH_WORDS planes of cap words: word w of slot s at paths[w * cap + s] */
-    uint32_t *nee;   /* NeeRec as NEE_WORDS planes */
-    int cap;
-};
-struct PassParams {
-    uint64_t seed;
-    int npix, width, height;
-    int sample_first, sample_step; /* sample of slot = sample_first + (slot / npix) * sample_step */
-    int integrator;
-};
-
-
-/* Path and direct-light records live in HBM as planes of 32-bit words (structure of arrays):
- * consecutive lanes work on consecutive slots, so every load / store of a field is one coalesced
- * request per wavefront; in registers a record is the plain struct. */
-#define PATH_WORDS ((int)(sizeof(PathRec) / 4))
-#define NEE_WORDS ((int)(sizeof(NeeRec) / 4))
-#define WORD_OF(T, field) ((int)(offsetof(T, field) / 4))
-template <int W0, int W1, typename T> PD void soa_load(const uint32_t *base, int cap, int slot, T *rec) {
-    uint32_t *o = reinterpret_cast<uint32_t *>(rec);
-#pragma unroll
-    for (int w = W0; w < W1; w++) o[w] = base[(size_t)w * cap + slot];
-}
-template <int W0, int W1, typename T> PD void soa_store(uint32_t *base, int cap, int slot, const T *rec) {
-    const uint32_t *o = reinterpret_cast<const uint32_t *>(rec);
-#pragma unroll
-    for (int w = W0; w < W1; w++) base[(size_t)w * cap + slot] = o[w];
-}
-#define NEE_A_BEGIN WORD_OF(NeeRec, fA)
-#define NEE_A_END WORD_OF(NeeRec, fB)
-#define NEE_B_BEGIN WORD_OF(NeeRec, fB)
-#define NEE_B_END WORD_OF(NeeRec, occA)
-#define NEE_RES_BEGIN WORD_OF(NeeRec, occA)
-#define NEE_RES_END (WORD_OF(NeeRec, tB) + 1)
-#define NEE_EXTRA_BEGIN WORD_OF(NeeRec, extra)
-#define NEE_EXTRA_END (WORD_OF(NeeRec, extra) + 3)
-PD void nee_load(const Pipe &pp, int slot, NeeRec *rec) { /* header, then only the halves in use */
-    soa_load<0, 4>(pp.nee, pp.cap, slot, rec);
-    if (rec->flags & NEE_A) soa_load<NEE_A_BEGIN, NEE_A_END>(pp.nee, pp.cap, slot, rec);
-    if (rec->flags & NEE_B) soa_load<NEE_B_BEGIN, NEE_B_END>(pp.nee, pp.cap, slot, rec);
-    if (rec->flags & NEE_EXTRA) soa_load<NEE_EXTRA_BEGIN, NEE_EXTRA_END>(pp.nee, pp.cap, slot, rec);
-}
-
-__device__ __forceinline__ unsigned wave_sum(unsigned v) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ void ctr_flush(unsigned long long *ctrs, int idx, unsigned v) {
-    unsigned s = wave_sum(v);
-    if (__lane_id() == 0 && s) atomicAdd(&ctrs[idx], (unsigned long long)s);
-}
-/* wave-aggregated append: one atomic per wavefront */
-__device__ __forceinline__ void queue_append(int *counter, int *queue, bool pred, int value) {
-    unsigned long long mask = __ballot(pred);
-    if (mask == 0) return;
-    int lane = __lane_id();
-    int leader = __ffsll((long long)mask) - 1;
-    int base = 0;
-    if (lane == leader) base = atomicAdd(counter, __popcll(mask));
-    base = __shfl(base, leader, 64);
-    if (pred) {
-        unsigned long long lower = mask & ((1ull << lane) - 1ull);
-        queue[base + __popcll(lower)] = value;
-    }
-}
-
-enum { C_TOTAL = 0, C_MISS, C_SURF, C_MED, C_LIGHT, C_ZERO, C_SHADOW, C_MIS, C_PROBE, C_CAMERA, C_NODES, C_PRIMS, C_COUNT };
 
 PD void camera_ray(const DCamera &c, const PassParams &pp, int pixel, int sample, f3 *o, f3 *d, float *weight) {
     int i = pixel % pp.width, j = pixel / pp.width;
@@ -165,31 +83,6 @@ __global__ void __launch_bounds__(TPB) k_raygen_only(DCamera cam, PassParams prm
     if (w_out) w_out[p] = w;
 }
 
-/* Aggregator::Intersect (ANY = false) / VisibilityTester::Unoccluded (ANY = true) over a queue of
- * rays: persistent wavefronts, see dev_trace.h */
-template <bool ANY, bool COUNT>
-__global__ void __launch_bounds__(TRACE_TPB) __attribute__((amdgpu_waves_per_eu(PT_WAVES, PT_WAVES))) k_ptrace(DScene sc, TraceIO io, unsigned long long *ctrs) {
-    __shared__ int s_stack[LDS_STACK * TRACE_TPB];
-    unsigned tn = 0, ti = 0;
-    persistent_trace<ANY, COUNT>(sc, io, &s_stack[threadIdx.x], &tn, &ti);
-    if (COUNT) {
-        ctr_flush(ctrs, C_NODES, tn);
-        ctr_flush(ctrs, C_PRIMS, ti);
-    }
-}
-
-/* grid-stride helper: every lane of a wavefront runs the same number of rounds, so the ballots of
- * queue_append / ctr_flush stay convergent; n may live in device memory (written by an earlier
- * kernel of the same stream) */
-#define GRID_STRIDE_BEGIN(n_ptr, n_host)                                                           \
-    const int n = (n_ptr) ? *(n_ptr) : (n_host);                                                   \
-    for (int base_ = blockIdx.x * TPB + (threadIdx.x & ~63); base_ < n; base_ += gridDim.x * TPB) { \
-        const int i = base_ + (threadIdx.x & 63);
-#define GRID_STRIDE_END }
-
-#ifndef SHADE_WAVES
-#define SHADE_WAVES 2
-#endif
 /* ---- bin the live paths by what they hit, so that a wavefront of k_shade runs one material's code
  * (miss / emitter / no material / the ten material types): two streaming passes, count then
  * scatter, wave-aggregated atomics per class.  The arithmetic of a path does not depend on where
@@ -237,127 +130,6 @@ __global__ void __launch_bounds__(TPB) k_bin_scatter(DScene sc, Pipe pp, const i
     GRID_STRIDE_END
 }
 
-/* SSS = true (scenes with a subsurface material): the BSSRDF tail of a vertex is traversed in
- * place, see dev_bssrdf.h; its occupancy is whatever the compiler can give it. */
-template <bool SSS>
-__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(SSS ? 1 : SHADE_WAVES, SSS ? 1 : SHADE_WAVES)))
-k_shade(DScene sc, Pipe pp, PassParams prm, const int *n_ptr, int n_host, const int *queue, int *q_next, int *q_nee, int *q_shadow, int *q_mis,
-        int *counts, int walk, unsigned long long *ctrs) {
-    __shared__ int s_stack[SSS ? LDS_STACK * TRACE_TPB : 1];
-    LaneStack ls;
-    ls.lds = &s_stack[SSS ? threadIdx.x : 0];
-    NeeCtr nctr;
-    nctr.shadow = nctr.mis = nctr.zero = 0;
-    unsigned probes = 0;
-    const SssCtx sss = {&ls, &nctr, &probes, walk != 0};
-    VertexCtr ctr;
-    ctr.total = ctr.miss = ctr.surf = ctr.med = ctr.light = ctr.zero = 0;
-    GRID_STRIDE_BEGIN(n_ptr, n_host)
-    bool alive = false, want_nee = false, want_shadow = false, want_mis = false;
-    int slot = 0;
-    if (i < n) {
-        slot = queue ? queue[i] : i;
-        int cap = pp.cap;
-        PathRec ps;
-        soa_load<0, PATH_WORDS>(pp.paths, cap, slot, &ps);
-        const NeeToPlanes rec = {reinterpret_cast<float *>(pp.nee), (size_t)cap, slot};
-        f3 ro(pp.ro[slot], pp.ro[cap + slot], pp.ro[2 * cap + slot]);
-        f3 rd(pp.rd[slot], pp.rd[cap + slot], pp.rd[2 * cap + slot]);
-        int pixel = slot % prm.npix;
-        int sample = prm.sample_first + (slot / prm.npix) * prm.sample_step;
-        Rng rng = make_rng(prm.seed, (uint32_t)pixel, (uint32_t)sample);
-        rng.dim = (uint32_t)ps.dim;
-        f3 L = ld3(ps.L), beta = ld3(ps.beta);
-        int med = ps.medium, bounces = ps.bounces, pflags = ps.flags;
-        VertexOut vo = shade_vertex<SSS>(sc, prm.integrator, rng, ro, rd, med, pp.hprim[slot], pp.hface[slot], pp.ht[slot], L, beta, bounces,
-                                         pflags, rec, ctr, &sss);
-        alive = vo.alive;
-        want_nee = vo.want_nee;
-        want_shadow = want_nee && (vo.nee_flags & NEE_A);
-        want_mis = want_nee && (vo.nee_flags & NEE_B);
-        if (SSS && vo.has_extra) {
-            if (want_nee) { /* keeps its place in L: after this vertex's own direct-light term */
-                rec.puti(NEE_W(flags), vo.nee_flags | NEE_EXTRA);
-                rec.put3(NEE_W(extra), vo.L_extra);
-            } else L += vo.L_extra;
-        }
-        st3(ps.L, L);
-        st3(ps.beta, beta);
-        ps.medium = med;
-        ps.bounces = bounces;
-        ps.flags = pflags;
-        ps.dim = (int)rng.dim;
-        soa_store<0, WORD_OF(PathRec, weight)>(pp.paths, cap, slot, &ps);
-        if (alive) {
-            pp.ro[slot] = ro.x; pp.ro[cap + slot] = ro.y; pp.ro[2 * cap + slot] = ro.z;
-            pp.rd[slot] = rd.x; pp.rd[cap + slot] = rd.y; pp.rd[2 * cap + slot] = rd.z;
-        }
-    }
-    queue_append(&counts[0], q_next, alive, slot);
-    queue_append(&counts[1], q_nee, want_nee, slot);
-    queue_append(&counts[2], q_shadow, want_shadow, slot);
-    queue_append(&counts[3], q_mis, want_mis, slot);
-    GRID_STRIDE_END
-    ctr_flush(ctrs, C_TOTAL, ctr.total);
-    ctr_flush(ctrs, C_MISS, ctr.miss);
-    ctr_flush(ctrs, C_SURF, ctr.surf);
-    ctr_flush(ctrs, C_MED, ctr.med);
-    ctr_flush(ctrs, C_LIGHT, ctr.light);
-    ctr_flush(ctrs, C_ZERO, ctr.zero);
-    if (SSS) {
-        ctr_flush(ctrs, C_SHADOW, nctr.shadow);
-        ctr_flush(ctrs, C_MIS, nctr.mis);
-        ctr_flush(ctrs, C_PROBE, probes);
-    }
-}
-
-/* direct-light stages with the walks of VisibilityTester::Tr / IntersectTr (scenes with medium
- * boundaries or emitters under Li_VolPath) */
-__global__ void __launch_bounds__(TPB) k_shadow_walk(DScene sc, Pipe pp, const int *n_ptr, int n_host, const int *queue,
-                                                     unsigned long long *ctrs) {
-    __shared__ int s_stack[LDS_STACK * TRACE_TPB];
-    LaneStack ls;
-    ls.lds = &s_stack[threadIdx.x];
-    NeeCtr ctr;
-    ctr.shadow = ctr.mis = ctr.zero = 0;
-    GRID_STRIDE_BEGIN(n_ptr, n_host)
-    if (i < n) {
-        const int slot = queue[i];
-        NeeRec rec;
-        nee_load(pp, slot, &rec);
-        nee_shadow<true>(sc, &rec, ctr, ls);
-        soa_store<WORD_OF(NeeRec, LiA), WORD_OF(NeeRec, LiA) + 3>(pp.nee, pp.cap, slot, &rec);
-    }
-    GRID_STRIDE_END
-    ctr_flush(ctrs, C_SHADOW, ctr.shadow);
-}
-
-__global__ void __launch_bounds__(TPB) k_mis_walk(DScene sc, Pipe pp, const int *n_ptr, int n_host, const int *queue,
-                                                  unsigned long long *ctrs) {
-    __shared__ int s_stack[LDS_STACK * TRACE_TPB];
-    LaneStack ls;
-    ls.lds = &s_stack[threadIdx.x];
-    NeeCtr ctr;
-    ctr.shadow = ctr.mis = ctr.zero = 0;
-    GRID_STRIDE_BEGIN(n_ptr, n_host)
-    if (i < n) {
-        int slot = queue[i];
-        NeeRec rec;
-        nee_load(pp, slot, &rec);
-        f3 Ld = nee_mis_resolve<true>(sc, rec, ctr, ls);
-        PathRec ps;
-        soa_load<0, 3>(pp.paths, pp.cap, slot, &ps);
-        f3 L = ld3(ps.L);
-        L += Ld;
-        if (rec.flags & NEE_EXTRA) L += ld3(rec.extra);
-        st3(ps.L, L);
-        soa_store<0, 3>(pp.paths, pp.cap, slot, &ps);
-    }
-    GRID_STRIDE_END
-    ctr_flush(ctrs, C_MIS, ctr.mis);
-    ctr_flush(ctrs, C_ZERO, ctr.zero);
-}
-
 /* sum of a direct-light record whose two rays went through the persistent tracer */
 __global__ void __launch_bounds__(TPB) k_nee_resolve(DScene sc, Pipe pp, const int *n_ptr, int n_host, const int *queue,
                                                      unsigned long long *ctrs) {
@@ -382,76 +154,6 @@ __global__ void __launch_bounds__(TPB) k_nee_resolve(DScene sc, Pipe pp, const i
     ctr_flush(ctrs, C_SHADOW, ctr.shadow);
     ctr_flush(ctrs, C_MIS, ctr.mis);
     ctr_flush(ctrs, C_ZERO, ctr.zero);
-}
-
-/* Finishes every path of the queue inside one launch: trace -> shade -> direct light -> ... until
- * the path ends (the loop of Li_* itself, main.cpp:105-410, one path per lane).  Used once the
- * wavefront stages have thinned the pass to a few per cent of its paths: from there on a bounce
- * is worth ~1e4 rays but would still cost three launches that each last as long as their longest
- * ray.  Same device functions, same order of operations per path as the staged kernels. */
-template <bool SSS>
-__global__ void __launch_bounds__(TPB) k_finish(DScene sc, Pipe pp, PassParams prm, const int *n_ptr, int n_host, const int *queue, int walk,
-                                                unsigned long long *ctrs) {
-    __shared__ int s_stack[LDS_STACK * TRACE_TPB];
-    LaneStack ls;
-    ls.lds = &s_stack[threadIdx.x];
-    VertexCtr ctr;
-    ctr.total = ctr.miss = ctr.surf = ctr.med = ctr.light = ctr.zero = 0;
-    NeeCtr nctr;
-    nctr.shadow = nctr.mis = nctr.zero = 0;
-    unsigned probes = 0;
-    const SssCtx sss = {&ls, &nctr, &probes, walk != 0};
-    GRID_STRIDE_BEGIN(n_ptr, n_host)
-    if (i < n) {
-        const int slot = queue ? queue[i] : i;
-        const int cap = pp.cap;
-        PathRec ps;
-        soa_load<0, PATH_WORDS>(pp.paths, cap, slot, &ps);
-        f3 ro(pp.ro[slot], pp.ro[cap + slot], pp.ro[2 * cap + slot]);
-        f3 rd(pp.rd[slot], pp.rd[cap + slot], pp.rd[2 * cap + slot]);
-        Rng rng = make_rng(prm.seed, (uint32_t)(slot % prm.npix), (uint32_t)(prm.sample_first + (slot / prm.npix) * prm.sample_step));
-        rng.dim = (uint32_t)ps.dim;
-        f3 L = ld3(ps.L), beta = ld3(ps.beta);
-        int med = ps.medium, bounces = ps.bounces, pflags = ps.flags;
-        NeeRec rec_local;
-        NeeRec *rec = &rec_local;
-        for (int guard = 0; guard < 100000; guard++) {
-            float tmax = kInfinity, b0 = 0, b1 = 0;
-            int hp = -1, hf = -1;
-            bool hit = traverse<false, false>(sc, ro, rd, tmax, hp, hf, b0, b1, nullptr, ls);
-            VertexOut vo = shade_vertex<SSS>(sc, prm.integrator, rng, ro, rd, med, hit ? hp : -1, hit ? hf : -1, tmax, L, beta, bounces, pflags, NeeToStruct{rec}, ctr, &sss);
-            if (vo.want_nee) {
-                f3 Ld;
-                if (walk) {
-                    if (rec->flags & NEE_A) nee_shadow<true>(sc, rec, nctr, ls);
-                    Ld = nee_mis_resolve<true>(sc, *rec, nctr, ls);
-                } else {
-                    if (rec->flags & NEE_A) nee_shadow<false>(sc, rec, nctr, ls);
-                    Ld = nee_mis_resolve<false>(sc, *rec, nctr, ls);
-                }
-                L += Ld;
-            }
-            if (SSS && vo.has_extra) L += vo.L_extra;
-            if (!vo.alive) break;
-        }
-        st3(ps.L, L);
-        st3(ps.beta, beta);
-        ps.medium = med;
-        ps.bounces = bounces;
-        ps.flags = pflags;
-        ps.dim = (int)rng.dim;
-        soa_store<0, WORD_OF(PathRec, weight)>(pp.paths, cap, slot, &ps);
-    }
-    GRID_STRIDE_END
-    ctr_flush(ctrs, C_TOTAL, ctr.total);
-    ctr_flush(ctrs, C_MISS, ctr.miss);
-    ctr_flush(ctrs, C_SURF, ctr.surf);
-    ctr_flush(ctrs, C_MED, ctr.med);
-    ctr_flush(ctrs, C_LIGHT, ctr.light);
-    ctr_flush(ctrs, C_ZERO, ctr.zero + nctr.zero);
-    ctr_flush(ctrs, C_SHADOW, nctr.shadow);
-    ctr_flush(ctrs, C_MIS, nctr.mis);
-    if (SSS) ctr_flush(ctrs, C_PROBE, probes);
 }
 
 /* Render()'s accumulation (main.cpp:449-455): we += weight * L per sample, in sample order */
@@ -646,9 +348,7 @@ static inline unsigned clampu(unsigned v, unsigned lo, unsigned hi) { return v <
 static void launch_ptrace(PtrContext *ctx, hipStream_t s, const TraceIO &io, int n_upper, bool any, bool count, int family) {
     unsigned blocks = clampu(nblocks(n_upper), 1, (unsigned)ctx->persist_blocks);
     ProfScope ps(ctx, s, family, (uint64_t)(io.n_ptr ? 0 : io.n));
-    if (any) hipLaunchKernelGGL((k_ptrace<true, false>), dim3(blocks), dim3(TRACE_TPB), 0, s, ctx->sc, io, ctx->ctrs);
-    else if (count) hipLaunchKernelGGL((k_ptrace<false, true>), dim3(blocks), dim3(TRACE_TPB), 0, s, ctx->sc, io, ctx->ctrs);
-    else hipLaunchKernelGGL((k_ptrace<false, false>), dim3(blocks), dim3(TRACE_TPB), 0, s, ctx->sc, io, ctx->ctrs);
+    rt_launch_ptrace(any, count, blocks, s, ctx->sc, io, ctx->ctrs);
 }
 static TraceIO soa_io(int n, const int *queue, long long plane, const float *o, const float *d, const float *tmax, int *prim, int *face,
                       float *t, float *b0, float *b1) {
@@ -700,12 +400,9 @@ static void enqueue_bounce(PtrContext *ctx, Lane &l, const PassParams &prm, cons
     {
         ProfScope ps(ctx, s, K_SHADE, (uint64_t)(n_ptr ? 0 : n_host));
         const int walk_i = prm.integrator == PTR_LI_VOLPATH && !ctx->scene_all_opaque ? 1 : 0;
-        if (ctx->scene_has_sss)
-            hipLaunchKernelGGL(k_shade<true>, dim3(stride_blocks), dim3(TPB), 0, s, ctx->sc, l.pipe, prm, n_ptr, n_host, q_shade, q_next, q_nee, q_shadow,
-                               q_mis, cnt, walk_i, ctx->ctrs);
-        else
-            hipLaunchKernelGGL(k_shade<false>, dim3(stride_blocks), dim3(TPB), 0, s, ctx->sc, l.pipe, prm, n_ptr, n_host, q_shade, q_next, q_nee, q_shadow,
-                               q_mis, cnt, walk_i, ctx->ctrs);
+        const ShadeArgs a = {ctx->sc, l.pipe, prm, n_ptr, n_host, q_shade, q_next, q_nee, q_shadow, q_mis, cnt, walk_i, ctx->ctrs};
+        if (ctx->scene_has_sss) rt_launch_shade_sss(stride_blocks, s, a);
+        else rt_launch_shade(stride_blocks, s, a);
     }
     /* the walks of VisibilityTester::Tr / IntersectTr can only go past their first hit under
      * Li_VolPath and only if some primitive has no material (medium boundary, emitter) */
@@ -713,11 +410,11 @@ static void enqueue_bounce(PtrContext *ctx, Lane &l, const PassParams &prm, cons
     if (walk) {
         {
             ProfScope ps(ctx, s, K_SHADOW, 0);
-            hipLaunchKernelGGL(k_shadow_walk, dim3(stride_blocks), dim3(TPB), 0, s, ctx->sc, l.pipe, (const int *)(cnt + 2), 0, (const int *)q_shadow, ctx->ctrs);
+            rt_launch_shadow_walk(stride_blocks, s, ctx->sc, l.pipe, (const int *)(cnt + 2), 0, (const int *)q_shadow, ctx->ctrs);
         }
         {
             ProfScope ps(ctx, s, K_MIS, 0);
-            hipLaunchKernelGGL(k_mis_walk, dim3(stride_blocks), dim3(TPB), 0, s, ctx->sc, l.pipe, (const int *)(cnt + 1), 0, (const int *)q_nee, ctx->ctrs);
+            rt_launch_mis_walk(stride_blocks, s, ctx->sc, l.pipe, (const int *)(cnt + 1), 0, (const int *)q_nee, ctx->ctrs);
         }
     } else {
         const char *nee = (const char *)l.pipe.nee;
@@ -804,12 +501,10 @@ static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int ste
         const bool walk = integrator == PTR_LI_VOLPATH && !ctx->scene_all_opaque;
         int upper = slots >> (staged < 6 ? staged : 6);
         ProfScope ps(ctx, s, K_FINISH, 0);
-        if (ctx->scene_has_sss)
-            hipLaunchKernelGGL(k_finish<true>, dim3(clampu(nblocks(upper), 32, 2048)), dim3(TPB), 0, s, ctx->sc, l.pipe, prm,
-                               (const int *)(l.counts + 4 * (staged - 1)), 0, q_cur, walk ? 1 : 0, ctx->ctrs);
-        else
-            hipLaunchKernelGGL(k_finish<false>, dim3(clampu(nblocks(upper), 32, 2048)), dim3(TPB), 0, s, ctx->sc, l.pipe, prm,
-                               (const int *)(l.counts + 4 * (staged - 1)), 0, q_cur, walk ? 1 : 0, ctx->ctrs);
+        const FinishArgs a = {ctx->sc, l.pipe, prm, (const int *)(l.counts + 4 * (staged - 1)), 0, q_cur, walk ? 1 : 0, ctx->ctrs};
+        const unsigned blocks = clampu(nblocks(upper), 32, 2048);
+        if (ctx->scene_has_sss) rt_launch_finish_sss(blocks, s, a);
+        else rt_launch_finish(blocks, s, a);
     }
     l.staged_used = staged;
     l.slots_used = slots;
@@ -931,6 +626,7 @@ int ptr_scene_upload(PtrContext *ctx, const PtrFlatScene *scene) {
     UP(uvidx, hs.uvidx)
     UP(order, hs.order)
     UP(top, hs.top)
+    UP(toy_tris, hs.toy_tris)
     UP(env_texels, hs.env_texels)
     UP(env_func, hs.env_func)
     UP(env_cdf, hs.env_cdf)

@@ -1,0 +1,133 @@
+/*
+ * rt_common.h — what the kernel translation units of the wavefront pipeline share: the per-pass
+ * buffers, record planes, queue / counter helpers, and the host-side launchers each unit exports.
+ * The kernels are split over several .hip files only so that they compile in parallel; device
+ * functions all live in the dev_*.h headers.
+ */
+#pragma once
+#include "dev_path.h"
+#include "dev_trace.h"
+#include <hip/hip_runtime.h>
+#include <cstddef>
+
+#define TPB 256
+#ifndef PT_WAVES
+#define PT_WAVES 5 /* wavefronts per SIMD the persistent tracer is compiled for */
+#endif
+
+struct Pipe {
+    float *ro, *rd;      /* 3 planes of cap floats each */
+    int *hprim, *hface;
+    float *ht;
+    uint32_t *paths; /* PathRec as PATH_WORDS planes of cap words: word w of slot s at paths[w * cap + s] */
+    uint32_t *nee;   /* NeeRec as NEE_WORDS planes */
+    int cap;
+};
+struct PassParams {
+    uint64_t seed;
+    int npix, width, height;
+    int sample_first, sample_step; /* sample of slot = sample_first + (slot / npix) * sample_step */
+    int integrator;
+};
+
+
+/* Path and direct-light records live in HBM as planes of 32-bit words (structure of arrays):
+ * consecutive lanes work on consecutive slots, so every load / store of a field is one coalesced
+ * request per wavefront; in registers a record is the plain struct. */
+#define PATH_WORDS ((int)(sizeof(PathRec) / 4))
+#define NEE_WORDS ((int)(sizeof(NeeRec) / 4))
+#define WORD_OF(T, field) ((int)(offsetof(T, field) / 4))
+template <int W0, int W1, typename T> PD void soa_load(const uint32_t *base, int cap, int slot, T *rec) {
+    uint32_t *o = reinterpret_cast<uint32_t *>(rec);
+#pragma unroll
+    for (int w = W0; w < W1; w++) o[w] = base[(size_t)w * cap + slot];
+}
+template <int W0, int W1, typename T> PD void soa_store(uint32_t *base, int cap, int slot, const T *rec) {
+    const uint32_t *o = reinterpret_cast<const uint32_t *>(rec);
+#pragma unroll
+    for (int w = W0; w < W1; w++) base[(size_t)w * cap + slot] = o[w];
+}
+#define NEE_A_BEGIN WORD_OF(NeeRec, fA)
+#define NEE_A_END WORD_OF(NeeRec, fB)
+#define NEE_B_BEGIN WORD_OF(NeeRec, fB)
+#define NEE_B_END WORD_OF(NeeRec, occA)
+#define NEE_RES_BEGIN WORD_OF(NeeRec, occA)
+#define NEE_RES_END (WORD_OF(NeeRec, tB) + 1)
+#define NEE_EXTRA_BEGIN WORD_OF(NeeRec, extra)
+#define NEE_EXTRA_END (WORD_OF(NeeRec, extra) + 3)
+PD void nee_load(const Pipe &pp, int slot, NeeRec *rec) { /* header, then only the halves in use */
+    soa_load<0, 4>(pp.nee, pp.cap, slot, rec);
+    if (rec->flags & NEE_A) soa_load<NEE_A_BEGIN, NEE_A_END>(pp.nee, pp.cap, slot, rec);
+    if (rec->flags & NEE_B) soa_load<NEE_B_BEGIN, NEE_B_END>(pp.nee, pp.cap, slot, rec);
+    if (rec->flags & NEE_EXTRA) soa_load<NEE_EXTRA_BEGIN, NEE_EXTRA_END>(pp.nee, pp.cap, slot, rec);
+}
+
+__device__ __forceinline__ unsigned wave_sum(unsigned v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ void ctr_flush(unsigned long long *ctrs, int idx, unsigned v) {
+    unsigned s = wave_sum(v);
+    if (__lane_id() == 0 && s) atomicAdd(&ctrs[idx], (unsigned long long)s);
+}
+/* wave-aggregated append: one atomic per wavefront */
+__device__ __forceinline__ void queue_append(int *counter, int *queue, bool pred, int value) {
+    unsigned long long mask = __ballot(pred);
+    if (mask == 0) return;
+    int lane = __lane_id();
+    int leader = __ffsll((long long)mask) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, __popcll(mask));
+    base = __shfl(base, leader, 64);
+    if (pred) {
+        unsigned long long lower = mask & ((1ull << lane) - 1ull);
+        queue[base + __popcll(lower)] = value;
+    }
+}
+
+enum { C_TOTAL = 0, C_MISS, C_SURF, C_MED, C_LIGHT, C_ZERO, C_SHADOW, C_MIS, C_PROBE, C_CAMERA, C_NODES, C_PRIMS, C_COUNT };
+
+/* grid-stride helper: every lane of a wavefront runs the same number of rounds, so the ballots of
+ * queue_append / ctr_flush stay convergent; n may live in device memory (written by an earlier
+ * kernel of the same stream) */
+#define GRID_STRIDE_BEGIN(n_ptr, n_host)                                                           \
+    const int n = (n_ptr) ? *(n_ptr) : (n_host);                                                   \
+    for (int base_ = blockIdx.x * TPB + (threadIdx.x & ~63); base_ < n; base_ += gridDim.x * TPB) { \
+        const int i = base_ + (threadIdx.x & 63);
+#define GRID_STRIDE_END }
+
+#ifndef SHADE_WAVES
+#define SHADE_WAVES 2
+#endif
+
+/* ---- launchers (one per kernel translation unit) ---- */
+struct ShadeArgs {
+    DScene sc;
+    Pipe pp;
+    PassParams prm;
+    const int *n_ptr;
+    int n_host;
+    const int *queue;
+    int *q_next, *q_nee, *q_shadow, *q_mis, *counts;
+    int walk;
+    unsigned long long *ctrs;
+};
+struct FinishArgs {
+    DScene sc;
+    Pipe pp;
+    PassParams prm;
+    const int *n_ptr;
+    int n_host;
+    const int *queue;
+    int walk;
+    unsigned long long *ctrs;
+};
+void rt_launch_shade(unsigned blocks, hipStream_t s, const ShadeArgs &a);      /* rt_shade.hip */
+void rt_launch_shade_sss(unsigned blocks, hipStream_t s, const ShadeArgs &a);  /* rt_shade_sss.hip */
+void rt_launch_finish(unsigned blocks, hipStream_t s, const FinishArgs &a);     /* rt_finish.hip */
+void rt_launch_finish_sss(unsigned blocks, hipStream_t s, const FinishArgs &a); /* rt_finish_sss.hip */
+void rt_launch_shadow_walk(unsigned blocks, hipStream_t s, const DScene &sc, const Pipe &pp, const int *n_ptr, int n_host, const int *queue,
+                           unsigned long long *ctrs); /* rt_walk.hip */
+void rt_launch_mis_walk(unsigned blocks, hipStream_t s, const DScene &sc, const Pipe &pp, const int *n_ptr, int n_host, const int *queue,
+                        unsigned long long *ctrs);
+void rt_launch_ptrace(bool any, bool count, unsigned blocks, hipStream_t s, const DScene &sc, const TraceIO &io, unsigned long long *ctrs); /* rt_trace.hip */

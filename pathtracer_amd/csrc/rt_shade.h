@@ -1,0 +1,87 @@
+/*
+ * rt_shade.h — the shade kernel: one loop iteration of the selected integrator per live path
+ * (main.cpp:72-410), see dev_path.h.  Instantiated in rt_shade.hip (SSS = false) and
+ * rt_shade_sss.hip (SSS = true).
+ */
+#pragma once
+#include "rt_common.h"
+
+/* SSS = true (scenes with a subsurface material): the BSSRDF tail of a vertex is traversed in
+ * place, see dev_bssrdf.h; its occupancy is whatever the compiler can give it. */
+template <bool SSS>
+__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(SSS ? 1 : SHADE_WAVES, SSS ? 1 : SHADE_WAVES)))
+k_shade(DScene sc, Pipe pp, PassParams prm, const int *n_ptr, int n_host, const int *queue, int *q_next, int *q_nee, int *q_shadow, int *q_mis,
+        int *counts, int walk, unsigned long long *ctrs) {
+    __shared__ int s_stack[SSS ? LDS_STACK * TRACE_TPB : 1];
+    LaneStack ls;
+    ls.lds = &s_stack[SSS ? threadIdx.x : 0];
+    NeeCtr nctr;
+    nctr.shadow = nctr.mis = nctr.zero = 0;
+    unsigned probes = 0;
+    const SssCtx sss = {&ls, &nctr, &probes, walk != 0};
+    VertexCtr ctr;
+    ctr.total = ctr.miss = ctr.surf = ctr.med = ctr.light = ctr.zero = 0;
+    GRID_STRIDE_BEGIN(n_ptr, n_host)
+    bool alive = false, want_nee = false, want_shadow = false, want_mis = false;
+    int slot = 0;
+    if (i < n) {
+        slot = queue ? queue[i] : i;
+        int cap = pp.cap;
+        PathRec ps;
+        soa_load<0, PATH_WORDS>(pp.paths, cap, slot, &ps);
+        const NeeToPlanes rec = {reinterpret_cast<float *>(pp.nee), (size_t)cap, slot};
+        f3 ro(pp.ro[slot], pp.ro[cap + slot], pp.ro[2 * cap + slot]);
+        f3 rd(pp.rd[slot], pp.rd[cap + slot], pp.rd[2 * cap + slot]);
+        int pixel = slot % prm.npix;
+        int sample = prm.sample_first + (slot / prm.npix) * prm.sample_step;
+        Rng rng = make_rng(prm.seed, (uint32_t)pixel, (uint32_t)sample);
+        rng.dim = (uint32_t)ps.dim;
+        f3 L = ld3(ps.L), beta = ld3(ps.beta);
+        int med = ps.medium, bounces = ps.bounces, pflags = ps.flags;
+        VertexOut vo = shade_vertex<SSS>(sc, prm.integrator, rng, ro, rd, med, pp.hprim[slot], pp.hface[slot], pp.ht[slot], L, beta, bounces,
+                                         pflags, rec, ctr, &sss);
+        alive = vo.alive;
+        want_nee = vo.want_nee;
+        want_shadow = want_nee && (vo.nee_flags & NEE_A);
+        want_mis = want_nee && (vo.nee_flags & NEE_B);
+        if (SSS && vo.has_extra) {
+            if (want_nee) { /* keeps its place in L: after this vertex's own direct-light term */
+                rec.puti(NEE_W(flags), vo.nee_flags | NEE_EXTRA);
+                rec.put3(NEE_W(extra), vo.L_extra);
+            } else L += vo.L_extra;
+        }
+        st3(ps.L, L);
+        st3(ps.beta, beta);
+        ps.medium = med;
+        ps.bounces = bounces;
+        ps.flags = pflags;
+        ps.dim = (int)rng.dim;
+        soa_store<0, WORD_OF(PathRec, weight)>(pp.paths, cap, slot, &ps);
+        if (alive) {
+            pp.ro[slot] = ro.x; pp.ro[cap + slot] = ro.y; pp.ro[2 * cap + slot] = ro.z;
+            pp.rd[slot] = rd.x; pp.rd[cap + slot] = rd.y; pp.rd[2 * cap + slot] = rd.z;
+        }
+    }
+    queue_append(&counts[0], q_next, alive, slot);
+    queue_append(&counts[1], q_nee, want_nee, slot);
+    queue_append(&counts[2], q_shadow, want_shadow, slot);
+    queue_append(&counts[3], q_mis, want_mis, slot);
+    GRID_STRIDE_END
+    ctr_flush(ctrs, C_TOTAL, ctr.total);
+    ctr_flush(ctrs, C_MISS, ctr.miss);
+    ctr_flush(ctrs, C_SURF, ctr.surf);
+    ctr_flush(ctrs, C_MED, ctr.med);
+    ctr_flush(ctrs, C_LIGHT, ctr.light);
+    ctr_flush(ctrs, C_ZERO, ctr.zero);
+    if (SSS) {
+        ctr_flush(ctrs, C_SHADOW, nctr.shadow);
+        ctr_flush(ctrs, C_MIS, nctr.mis);
+        ctr_flush(ctrs, C_PROBE, probes);
+    }
+}
+
+
+template <bool SSS> static void rt_launch_shade_t(unsigned blocks, hipStream_t s, const ShadeArgs &a) {
+    hipLaunchKernelGGL(k_shade<SSS>, dim3(blocks), dim3(TPB), 0, s, a.sc, a.pp, a.prm, a.n_ptr, a.n_host, a.queue, a.q_next, a.q_nee, a.q_shadow,
+                       a.q_mis, a.counts, a.walk, a.ctrs);
+}

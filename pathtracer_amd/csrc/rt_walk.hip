@@ -1,0 +1,62 @@
+/*
+ * rt_walk.hip — direct-light stages for scenes where a shadow / MIS ray may pass through
+ * primitives (medium boundaries, emitters under Li_VolPath): the walks are traversed in-kernel.
+ */
+#include "rt_common.h"
+
+/* direct-light stages with the walks of VisibilityTester::Tr / IntersectTr (scenes with medium
+ * boundaries or emitters under Li_VolPath) */
+__global__ void __launch_bounds__(TPB) k_shadow_walk(DScene sc, Pipe pp, const int *n_ptr, int n_host, const int *queue,
+                                                     unsigned long long *ctrs) {
+    __shared__ int s_stack[LDS_STACK * TRACE_TPB];
+    LaneStack ls;
+    ls.lds = &s_stack[threadIdx.x];
+    NeeCtr ctr;
+    ctr.shadow = ctr.mis = ctr.zero = 0;
+    GRID_STRIDE_BEGIN(n_ptr, n_host)
+    if (i < n) {
+        const int slot = queue[i];
+        NeeRec rec;
+        nee_load(pp, slot, &rec);
+        nee_shadow<true>(sc, &rec, ctr, ls);
+        soa_store<WORD_OF(NeeRec, LiA), WORD_OF(NeeRec, LiA) + 3>(pp.nee, pp.cap, slot, &rec);
+    }
+    GRID_STRIDE_END
+    ctr_flush(ctrs, C_SHADOW, ctr.shadow);
+}
+
+__global__ void __launch_bounds__(TPB) k_mis_walk(DScene sc, Pipe pp, const int *n_ptr, int n_host, const int *queue,
+                                                  unsigned long long *ctrs) {
+    __shared__ int s_stack[LDS_STACK * TRACE_TPB];
+    LaneStack ls;
+    ls.lds = &s_stack[threadIdx.x];
+    NeeCtr ctr;
+    ctr.shadow = ctr.mis = ctr.zero = 0;
+    GRID_STRIDE_BEGIN(n_ptr, n_host)
+    if (i < n) {
+        int slot = queue[i];
+        NeeRec rec;
+        nee_load(pp, slot, &rec);
+        f3 Ld = nee_mis_resolve<true>(sc, rec, ctr, ls);
+        PathRec ps;
+        soa_load<0, 3>(pp.paths, pp.cap, slot, &ps);
+        f3 L = ld3(ps.L);
+        L += Ld;
+        if (rec.flags & NEE_EXTRA) L += ld3(rec.extra);
+        st3(ps.L, L);
+        soa_store<0, 3>(pp.paths, pp.cap, slot, &ps);
+    }
+    GRID_STRIDE_END
+    ctr_flush(ctrs, C_MIS, ctr.mis);
+    ctr_flush(ctrs, C_ZERO, ctr.zero);
+}
+
+
+void rt_launch_shadow_walk(unsigned blocks, hipStream_t s, const DScene &sc, const Pipe &pp, const int *n_ptr, int n_host, const int *queue,
+                           unsigned long long *ctrs) {
+    hipLaunchKernelGGL(k_shadow_walk, dim3(blocks), dim3(TPB), 0, s, sc, pp, n_ptr, n_host, queue, ctrs);
+}
+void rt_launch_mis_walk(unsigned blocks, hipStream_t s, const DScene &sc, const Pipe &pp, const int *n_ptr, int n_host, const int *queue,
+                        unsigned long long *ctrs) {
+    hipLaunchKernelGGL(k_mis_walk, dim3(blocks), dim3(TPB), 0, s, sc, pp, n_ptr, n_host, queue, ctrs);
+}

@@ -174,6 +174,46 @@ void ZooScene(Camera *camera, Float aspect, int variant) {
     if (variant & 2) InsertCameraMedium(MakeMedium(Spectrum(.004), Spectrum(.012), 0.3));
 }
 
+/* OrigamiScene (main.cpp:854-911): the four signed-distance toys with per-face PlayGround colours
+ * over a matte ground, under the generated sky (the reference loads skylight-sunset.exr) */
+void OrigamiScene(Camera *camera, Float aspect) {
+    camera->Config(Point3f(0.f, 62.f, 70.f), Point3f(-10, 23, 0), vec3f(0.f, 1.f, 0.f), 50.f, aspect);
+    std::vector<Spectrum> boatSpectrums({SpectrumFromURGB(139, 69, 19), Spectrum(.87, .12, .27), SpectrumFromURGB(244, 164, 96)});
+    std::vector<Spectrum> whaleSpectrums({Spectrum(.02, .21, .54), Spectrum(.1, .32, .76), Spectrum(.86, .86, .98)});
+    MaterialDescriptor gray = MakeMatteMaterial(Spectrum(0.9, 0.9, 0.7));
+    MaterialDescriptor dragonMat = MakePlayGroundMaterial(Spectrum(.85, .12, .02));
+    MaterialDescriptor boatMat = MakePlayGroundMaterial(boatSpectrums);
+    MaterialDescriptor whaleMat = MakePlayGroundMaterial(whaleSpectrums);
+    MaterialDescriptor birdMat = MakePlayGroundMaterial(Spectrum(.85, .42, .52));
+    InsertPrimitive(MakeRectangle(Translate(0, 0, 0) * RotateX(90), 2000, 2000), gray);
+    static std::vector<Spectrum> sky;
+    if (sky.empty()) sky = MakeSky(256, 128);
+    InsertLightMap(sky.data(), 256, 128, RotateX(-90) * RotateZ(90), Spectrum(2.5));
+    Float len = 15;
+    Float h = 1.5;
+    Float h2 = h * 0.5 * len;
+    Transform transf = Translate(-len * 0.5, h2 * 0.93, 0) * RotateX(-20);
+    Float depth = 0.5;
+    Bounds3f bound(Point3f(-len, -h2, -depth), Point3f(len, h2, depth));
+    ProcToyDescriptor dragon = MakeProceduralToy(transf, bound, 1);
+    transf = Translate(-len * 2.5, h2 * 0.93, len);
+    ProcToyDescriptor whale = MakeProceduralToy(transf, bound, 2);
+    len = 19;
+    h = 2.0;
+    h2 = h * 0.5 * len;
+    transf = Translate(-len * 0.5, h2, -len) * RotateY(60);
+    bound = Bounds3f(Point3f(-len, -h2, -len), Point3f(len, h2, len));
+    ProcToyDescriptor boat = MakeProceduralToy(transf, bound, 0);
+    InsertPrimitive(dragon, dragonMat);
+    InsertPrimitive(boat, boatMat);
+    InsertPrimitive(whale, whaleMat);
+    Bounds3f bo2(Point3f(-len, -len, -len), Point3f(len, len, len));
+    transf = Translate(-3 * len, 2.0 * len, -len) * RotateY(-45);
+    InsertPrimitive(MakeProceduralToy(transf, bo2, 3), birdMat);
+    transf = Translate(len, 1.6 * len, -len * 0.5) * RotateY(200);
+    InsertPrimitive(MakeProceduralToy(transf, bo2, 3), dragonMat);
+}
+
 /* c5 (volume half): VolumetricCausticsScene verbatim, main.cpp:987-1021 */
 void VolumetricCausticsScene(Camera *camera, Float aspect) {
     camera->Config(Point3f(0.f, 18.f, 70.f), Point3f(0, 21.15341, 0), vec3f(0.f, 1.f, 0.f), 40.f, aspect);
@@ -269,7 +309,7 @@ struct BuiltScene {
 
 extern "C" {
 
-/* name: "cornell" | "knot" | "zoo" | "volcaustic" | "fluid" | "subsurface"; p0/p1: size and variant */
+/* name: "cornell" | "knot" | "zoo" | "volcaustic" | "fluid" | "subsurface" | "origami"; p0/p1: size and variant */
 void *pth_scene_build(const char *name, int width, int height, int p0, int p1) {
     std::string n(name);
     BuiltScene *b = new BuiltScene();
@@ -284,6 +324,7 @@ void *pth_scene_build(const char *name, int width, int height, int p0, int p1) {
     else if (n == "volcaustic") VolumetricCausticsScene(&b->camera, aspect);
     else if (n == "fluid") FluidScene(&b->camera, aspect, p0 > 0 ? p0 : 4000000);
     else if (n == "subsurface") SubsurfaceScene(&b->camera, aspect, p0);
+    else if (n == "origami") OrigamiScene(&b->camera, aspect);
     else { delete b; return nullptr; }
     b->flat = FlattenScene();
     return b;

@@ -17,6 +17,7 @@ SCENES = {
     "zoo_sky_fog": ("zoo", 0, 3),
     "volcaustic": ("volcaustic", 0, 0),
     "fluid": ("fluid", 3000, 0),
+    "origami": ("origami", 0, 0),
     "subsurface": ("subsurface", 0, 0),
     "subsurface_knot": ("subsurface", 8, 0),
 }
