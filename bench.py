@@ -31,6 +31,25 @@ def ray_count(c):
     return c["total_paths"] + c["shadow_rays"] + c["mis_rays"] + c["probe_rays"]
 
 
+def measured_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the newest committed PMC summary
+    (profiles/r*_summary.json, written by tools/gpu_profile.sh -> tools/prof_summary.py --json from
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command).  rocprofv3 reports KB;
+    on gfx950 FETCH_SIZE tallies 128-B requests at 64 B, hence the factor 2 (MI355X_MICROARCH.md, HBM section).
+    Returns (bytes_per_launch, source) or (None, None)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")))
+    if not files:
+        return None, None
+    try:
+        k = json.load(open(files[-1])).get(kernel)
+        c = k["counters"]
+        n = max(1, int(k.get("dispatches") or k.get("calls") or 1))
+        return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 / n, os.path.relpath(files[-1], ROOT)
+    except Exception:
+        return None, None
+
+
 def cpu_baseline(scene, width, height, integrator, seed):
     """The oracle (CPU restatement of the reference path) on this box's host cores, bounded sample."""
     from oracle import orc
@@ -155,6 +174,7 @@ def main():
         avg_ms = tk["total_ms"] / launches
         rays_per_launch = c["total_paths"] / launches  # every path segment is one ray of this kernel
         achieved = bytes_per_ray * rays_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic, traffic_src = measured_traffic("k_ptrace<false, false>")
         out = {
             "metric": "Mrays/s (incoherent bounces)",
             "value": rays_all / dt_max / 1e6,
@@ -177,8 +197,9 @@ def main():
                        "scene_upload_s": round(t_up, 3), "parallelism": "samples round-robin over %d GPU(s), scene replicated" % world},
             "samples_per_s": cam_all / dt_max,
             "rays_per_sample": rays_all / max(1.0, cam_all),
-            "roofline": {"bound": "hbm", "kernel": "k_trace_closest", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": "k_ptrace<false, false> (closest hit)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": bytes_per_ray * rays_per_launch,
                          "bytes_per_ray": bytes_per_ray, "nodes_per_ray": nodes_per_ray, "items_per_ray": items_per_ray,
                          "avg_launch_ms": avg_ms, "rays_per_launch": rays_per_launch, "launches": tk["launches"]},
             "kernels_ms": {k: round(v["total_ms"], 3) for k, v in prof.items() if v["launches"]},

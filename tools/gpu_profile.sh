@@ -16,7 +16,7 @@ for P in "sq:SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIV
   timeout -s KILL 240 rocprofv3 --pmc $CTRS --output-format csv -d $OUT/$NAME -o p -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS > $OUT/$NAME.log 2>&1 || { echo "pmc pass $NAME failed"; tail -5 $OUT/$NAME.log; exit 1; }
   echo "pass $NAME ok"
 done
-cd $GRAFT_REPO_ROOT && python3 tools/prof_summary.py $OUT/trace $OUT/sq $OUT/sq2 $OUT/tcc $OUT/fetch $OUT/write > $OUT/summary.txt
+cd $GRAFT_REPO_ROOT && python3 tools/prof_summary.py --json $OUT/summary.json $OUT/trace $OUT/sq $OUT/sq2 $OUT/tcc $OUT/fetch $OUT/write > $OUT/summary.txt
 # keep only the summaries small enough to merge back
 find $OUT -name "*.csv" -size +20M -delete
 tail -60 $OUT/summary.txt
