@@ -53,6 +53,41 @@ PD bool slab_test(const float *bmin, const float *bmax, const f3 &o, const f3 &i
     return true;
 }
 
+/* the same test on a box given by scalars (a child slot of a 4-wide node) */
+PD bool slab_test6(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, const f3 &o, const f3 &inv, float tmax, float *t_entry) {
+    const float bmin[3] = {mnx, mny, mnz}, bmax[3] = {mxx, mxy, mxz};
+    return slab_test(bmin, bmax, o, inv, tmax, t_entry);
+}
+
+/* One visit of a 4-wide node (dev_scene.h Node128): tests the occupied child slots and leaves the
+ * refs of those the ray enters in r0..r3, nearest first (BVH_NO_CHILD pads the tail).  A sorting
+ * network over (entry distance, ref) pairs keeps everything in registers. */
+#define BVH4_CSWAP(ta, ra, tb, rb)      \
+    do {                                \
+        if (tb < ta) {                  \
+            float ts_ = ta; ta = tb; tb = ts_; \
+            int rs_ = ra; ra = rb; rb = rs_;   \
+        }                               \
+    } while (0)
+PD int bvh4_visit(const Node128 *nodes, int node, const f3 &ro, const f3 &inv, float tmax, int &r0, int &r1, int &r2, int &r3, unsigned *tested) {
+    const float4 *np = reinterpret_cast<const float4 *>(nodes + node);
+    const float4 mnx = np[0], mny = np[1], mnz = np[2], mxx = np[3], mxy = np[4], mxz = np[5];
+    const float4 chf = np[6];
+    r0 = __float_as_int(chf.x); r1 = __float_as_int(chf.y); r2 = __float_as_int(chf.z); r3 = __float_as_int(chf.w);
+    float t0 = kInfinity, t1 = kInfinity, t2 = kInfinity, t3 = kInfinity;
+    if (tested) *tested += (r0 != BVH_NO_CHILD) + (r1 != BVH_NO_CHILD) + (r2 != BVH_NO_CHILD) + (r3 != BVH_NO_CHILD);
+    if (!(r0 != BVH_NO_CHILD && slab_test6(mnx.x, mny.x, mnz.x, mxx.x, mxy.x, mxz.x, ro, inv, tmax, &t0))) { r0 = BVH_NO_CHILD; t0 = kInfinity; }
+    if (!(r1 != BVH_NO_CHILD && slab_test6(mnx.y, mny.y, mnz.y, mxx.y, mxy.y, mxz.y, ro, inv, tmax, &t1))) { r1 = BVH_NO_CHILD; t1 = kInfinity; }
+    if (!(r2 != BVH_NO_CHILD && slab_test6(mnx.z, mny.z, mnz.z, mxx.z, mxy.z, mxz.z, ro, inv, tmax, &t2))) { r2 = BVH_NO_CHILD; t2 = kInfinity; }
+    if (!(r3 != BVH_NO_CHILD && slab_test6(mnx.w, mny.w, mnz.w, mxx.w, mxy.w, mxz.w, ro, inv, tmax, &t3))) { r3 = BVH_NO_CHILD; t3 = kInfinity; }
+    BVH4_CSWAP(t0, r0, t1, r1);
+    BVH4_CSWAP(t2, r2, t3, r3);
+    BVH4_CSWAP(t0, r0, t2, r2);
+    BVH4_CSWAP(t1, r1, t3, r3);
+    BVH4_CSWAP(t1, r1, t2, r2);
+    return (r0 != BVH_NO_CHILD) + (r1 != BVH_NO_CHILD) + (r2 != BVH_NO_CHILD) + (r3 != BVH_NO_CHILD);
+}
+
 /* ---- triangle, mesh.cpp:162-249 (watertight test, double fallback for zero edge functions) ----
  * The permutation and shear depend on the ray only (mesh.cpp:176-186); the reference recomputes
  * them for every triangle, here they are set up once per ray - same operations, same values. */
@@ -303,9 +338,10 @@ PD bool shape_hit_t(const DScene &sc, const DPrim &pr, const f3 &ro, const f3 &r
  *        order in which primitives are met (an SDF hit distance is measured along the normalised
  *        direction and can inflate tMax of a non-unit shadow ray, procedural.cpp:238; a
  *        rectangle's hit can lie in front of its bounds, rectangle.cpp:8 vs :37-40).
- *  geom  meshes and particle clouds: one SAH-built BVH each, 64-byte nodes carrying both
- *        children's boxes, 48-byte pre-gathered leaf records, near child first (replaces the
- *        nested loops of mesh.cpp:454-509 and particlecloud.cpp:197-274).
+ *  geom  meshes and particle clouds: one SAH-built BVH each, collapsed to 4-wide 128-byte nodes
+ *        (the four children's boxes in one line), 48-byte pre-gathered leaf records, children
+ *        visited nearest first (replaces the nested loops of mesh.cpp:454-509 and
+ *        particlecloud.cpp:197-274).
  *
  * Closest hit: the reference accepts t <= tMax, so of two hits at bit-equal t the later tested
  * wins; inside a mesh that depends on its BVH - the oracle reports such rays and the tests
@@ -341,24 +377,15 @@ PD bool bvh_closest(const DScene &sc, int root, const f3 &ro, const f3 &rd, cons
     while (true) {
         /* descend until this lane holds a leaf (or has nothing left) */
         while (node >= 0 && node != DONE) {
-            const float4 *np = reinterpret_cast<const float4 *>(sc.nodes + node);
-            float4 a = np[0], b = np[1], c = np[2], d = np[3];
-            float lmin[3] = {a.x, a.y, a.z}, lmax[3] = {a.w, b.x, b.y};
-            float rmin[3] = {b.z, b.w, c.x}, rmax[3] = {c.y, c.z, c.w};
-            int left = __float_as_int(d.x), right = __float_as_int(d.y);
-            float tl, tr0;
-            bool hl = slab_test(lmin, lmax, ro, inv, tmax, &tl);
-            bool hr = slab_test(rmin, rmax, ro, inv, tmax, &tr0);
-            if (COUNT) st->nodes += 2;
-            if (hl && hr) {
-                int first = left, second = right;
-                if (tr0 < tl) { first = right; second = left; }
-                STACK_PUSH(second);
-                node = first;
-            } else if (hl) node = left;
-            else if (hr) node = right;
-            else if (sp == 0) node = DONE;
-            else node = STACK_POP();
+            int r0, r1, r2, r3;
+            const int nh = bvh4_visit(sc.nodes, node, ro, inv, tmax, r0, r1, r2, r3, COUNT ? &st->nodes : nullptr);
+            if (nh == 0) node = sp == 0 ? DONE : STACK_POP();
+            else {
+                if (nh > 3) STACK_PUSH(r3);
+                if (nh > 2) STACK_PUSH(r2);
+                if (nh > 1) STACK_PUSH(r1);
+                node = r0;
+            }
         }
         if (node == DONE) break;
         {

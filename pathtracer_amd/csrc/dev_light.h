@@ -38,14 +38,26 @@ PD f3 env_lookup(const DScene &sc, const f2 &st) {
 }
 
 /* ---- sampling.h:19-77 ---- */
-PD int find_interval_cdf(const float *cdf, int size, float u) { /* geometry.h:1091-1107 with pred cdf[i] <= u */
-    int first = 0, len = size;
-    while (len > 0) {
-        int half = len >> 1, middle = first + half;
-        if (cdf[middle] <= u) { first = middle + 1; len -= half + 1; }
-        else len = half;
+/* geometry.h:1091-1107 with pred cdf[i] <= u: the number of leading entries <= u, minus one, clamped.
+ * The reference bisects (10-11 dependent loads per lookup on a 512 x 1024 light map, two lookups
+ * per light sample: the longest dependent-load chain of the shade kernel).  The entries are
+ * non-decreasing, so the partition point is unique and an 8-ary search finds the same index with
+ * seven independent loads per round: 4 rounds instead of 11. */
+PD int find_interval_cdf(const float *cdf, int size, float u) {
+    int lo = 0, hi = size; /* cdf[i] <= u for all i < lo, cdf[i] > u for all i >= hi */
+    while (hi - lo > 7) {
+        const int step = (hi - lo) >> 3;
+        int c = 0;
+#pragma unroll
+        for (int j = 1; j <= 7; j++) c += cdf[lo + j * step] <= u ? 1 : 0;
+        const int base = lo;
+        if (c < 7) hi = base + (c + 1) * step;
+        if (c > 0) lo = base + c * step + 1;
     }
-    return clampi(first - 1, 0, size - 2);
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < 7; j++) c += (lo + j < hi && cdf[lo + j] <= u) ? 1 : 0;
+    return clampi(lo + c - 1, 0, size - 2);
 }
 PD float d1_sample(const float *func, const float *cdf, float funcInt, int size, float u, float *pdf, int *off) {
     int offset = find_interval_cdf(cdf, size, u);

@@ -11,14 +11,15 @@ enum { PF_FLIP_N = 1, PF_REVERSE = 2, PF_EMISSIVE = 4 };
 enum { ITEM_TRI = 0, ITEM_PARTICLE = 1, ITEM_PRIM = 2 };
 enum { LT_AREA = 1, LT_DISTANT = 2, LT_INFINITE = 3 };
 
-/* Compact BVH node, 64 B = one 64-byte line: both children's boxes + refs, so one fetch serves
- * two slab tests.  ref >= 0: index of an inner node; ref < 0: leaf, -(ref+1) = first | (n-1)<<27;
- * an absent child has n = 0 encoded as ref = INT32_MIN. */
-struct Node64 {
-    float lmin[3], lmax[3];
-    float rmin[3], rmax[3];
-    int32_t left, right;
-    int32_t pad[2];
+/* Inner node of a geometry BVH: FOUR children per node, 128 B = one L2 line.  Component planes of
+ * the four child boxes (7 x float4 loads per visit), child refs: >= 0 inner node index, < 0 leaf
+ * `-(first | (n-1) << 27) - 1` over items[], BVH_NO_CHILD = empty slot.  Made by collapsing the
+ * binned-SAH binary tree (ptr_build.cpp): half as many dependent node fetches per ray as a binary
+ * tree, and every byte of the fetched line is used. */
+struct Node128 {
+    float mnx[4], mny[4], mnz[4], mxx[4], mxy[4], mxz[4];
+    int32_t child[4];
+    int32_t pad[4];
 };
 /* Node of the top-level BVH over primitives: the reference's own tree (primitive.cpp:537-582),
  * kept because a few results depend on its visiting order.  Leaf: left = -1, handles
@@ -33,7 +34,7 @@ struct TopNode {
 #define TOP_STACK 48
 #define BVH_NO_CHILD INT32_MIN
 #define BVH_MAX_LEAF 4
-#define BVH_STACK 64
+#define BVH_STACK 96 /* entries per lane: up to 3 pushes per level of a 4-wide tree */
 
 /* Leaf record, 48 B (3 x float4), pre-gathered so a leaf test needs no indirection:
  *  TRI      : q0 = (p0, prim)  q1 = (p1, tri)       q2 = (p2, ITEM_TRI)
@@ -105,7 +106,7 @@ struct DTable { /* BSSRDFTable, bssrdf.h:29-42 (100 x 64) */
 };
 
 struct DScene {
-    const Node64 *nodes;
+    const Node128 *nodes;
     const Item48 *items;
     const DPrim *prims;
     const DMat *mats;

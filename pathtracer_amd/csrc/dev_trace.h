@@ -8,8 +8,8 @@
  * spends ~20x the mean).  Here a wavefront is persistent: a lane whose ray has ended takes the
  * next ray from the queue (64 indices per atomic, handed out by ballot rank), so a long ray
  * occupies one lane, not a wavefront.  Each ray still sees exactly the operations of traverse<>:
- * top level = the reference's own primitive BVH walked in its order, geometry level = SAH BVH,
- * near child first, closest-hit rule t <= tMax.
+ * top level = the reference's own primitive BVH walked in its order, geometry level = 4-wide SAH
+ * BVH, nearest child first, closest-hit rule t <= tMax.
  */
 #pragma once
 #include "dev_isect.h"
@@ -193,24 +193,17 @@ PD void persistent_trace(const DScene &sc, const TraceIO &io, int *lds, unsigned
 
         /* ---- geometry level: inner nodes until a leaf ---- */
         while (mode == TM_GEOM && node >= 0) {
-            const float4 *np = reinterpret_cast<const float4 *>(sc.nodes + node);
-            float4 a = np[0], b = np[1], c = np[2], d = np[3];
-            float lmin[3] = {a.x, a.y, a.z}, lmax[3] = {a.w, b.x, b.y};
-            float rmin[3] = {b.z, b.w, c.x}, rmax[3] = {c.y, c.z, c.w};
-            int left = __float_as_int(d.x), right = __float_as_int(d.y);
-            float tl, tr0;
-            bool hl = slab_test(lmin, lmax, ro, inv, tmax, &tl);
-            bool hr = slab_test(rmin, rmax, ro, inv, tmax, &tr0);
-            if (COUNT) rn += 2;
-            if (hl && hr) {
-                int first = left, second = right;
-                if (tr0 < tl) { first = right; second = left; }
-                PT_PUSH(second);
-                node = first;
-            } else if (hl) node = left;
-            else if (hr) node = right;
-            else if (sp == sp_base) mode = TM_TOPLEAF;
-            else node = PT_POP();
+            int r0, r1, r2, r3;
+            const int nh = bvh4_visit(sc.nodes, node, ro, inv, tmax, r0, r1, r2, r3, COUNT ? &rn : nullptr);
+            if (nh == 0) {
+                if (sp == sp_base) mode = TM_TOPLEAF;
+                else node = PT_POP();
+            } else {
+                if (nh > 3) PT_PUSH(r3);
+                if (nh > 2) PT_PUSH(r2);
+                if (nh > 1) PT_PUSH(r1);
+                node = r0;
+            }
             if (__popcll(__ballot(mode == TM_GEOM && node >= 0)) < PT_MIN_ACTIVE) break;
         }
 

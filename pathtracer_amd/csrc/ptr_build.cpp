@@ -79,6 +79,13 @@ DMedium conv_medium(const PtrMedium &pm) {
 inline float as_float(int32_t v) { float f; memcpy(&f, &v, 4); return f; }
 
 /* ---- binned SAH build ----------------------------------------------------------------- */
+/* node of the intermediate binary SAH tree (host only; collapsed into Node128 below) */
+struct Node64 {
+    float lmin[3], lmax[3];
+    float rmin[3], rmax[3];
+    int32_t left, right;
+};
+
 struct Builder {
     const std::vector<Box> &boxes;
     std::vector<uint32_t> idx;
@@ -196,8 +203,58 @@ struct Builder {
         for (int i = 0; i < 3; i++) { nd.lmin[i] = lb.mn[i]; nd.lmax[i] = lb.mx[i]; nd.rmin[i] = rb.mn[i]; nd.rmax[i] = rb.mx[i]; }
         nd.left = l;
         nd.right = r;
-        nd.pad[0] = nd.pad[1] = 0;
         return me_global;
+    }
+};
+
+/* Binary SAH tree -> 4-wide nodes: starting from a node's two children, the inner child with the
+ * largest surface area is replaced by its own two children until four slots are taken (or only
+ * leaves remain).  Leaves and their item ranges are kept as they are. */
+struct Collapser {
+    const std::vector<Node64> &bin; /* refs >= 0 index this vector */
+    std::vector<Node128> &out;      /* refs >= 0 written here index this vector (global) */
+    int max_depth = 0;
+    Collapser(const std::vector<Node64> &b, std::vector<Node128> &o) : bin(b), out(o) {}
+    struct Slot { Box box; int32_t ref; };
+    static Box box_of(const float *mn, const float *mx) {
+        Box b;
+        for (int a = 0; a < 3; a++) { b.mn[a] = mn[a]; b.mx[a] = mx[a]; }
+        return b;
+    }
+    int32_t emit(int32_t ref, int depth) {
+        if (ref < 0) return ref;
+        if (depth > max_depth) max_depth = depth;
+        Slot sl[4];
+        int n = 2;
+        {
+            const Node64 &nd = bin[ref];
+            sl[0] = Slot{box_of(nd.lmin, nd.lmax), nd.left};
+            sl[1] = Slot{box_of(nd.rmin, nd.rmax), nd.right};
+        }
+        while (n < 4) {
+            int pick = -1;
+            float area = -1;
+            for (int i = 0; i < n; i++)
+                if (sl[i].ref >= 0 && sl[i].box.half_area() > area) { area = sl[i].box.half_area(); pick = i; }
+            if (pick < 0) break;
+            const Node64 &ch = bin[sl[pick].ref];
+            sl[pick] = Slot{box_of(ch.lmin, ch.lmax), ch.left};
+            sl[n++] = Slot{box_of(ch.rmin, ch.rmax), ch.right};
+        }
+        const size_t me = out.size();
+        out.emplace_back();
+        int32_t refs[4];
+        for (int i = 0; i < n; i++) refs[i] = emit(sl[i].ref, depth + 1);
+        Node128 &o = out[me];
+        memset(&o, 0, sizeof(o));
+        for (int i = 0; i < 4; i++) {
+            if (i < n) {
+                o.mnx[i] = sl[i].box.mn[0]; o.mny[i] = sl[i].box.mn[1]; o.mnz[i] = sl[i].box.mn[2];
+                o.mxx[i] = sl[i].box.mx[0]; o.mxy[i] = sl[i].box.mx[1]; o.mxz[i] = sl[i].box.mx[2];
+                o.child[i] = refs[i];
+            } else o.child[i] = BVH_NO_CHILD;
+        }
+        return (int32_t)me;
     }
 };
 
@@ -349,13 +406,16 @@ int ptr_flatten(const PtrFlatScene *fs, HostScene *hs, std::string *err) {
     auto build_geom = [&](const std::vector<Box> &boxes, const std::vector<Item48> &raw, int32_t *root, Box *bound) -> int {
         if (boxes.empty()) return PTR_OK;
         if (hs->items.size() + boxes.size() >= (1u << 27)) return fail(err, PTR_ERR_LIMIT, "more than 2^27 BVH items");
-        Builder b(boxes, hs->nodes.size(), hs->items.size());
+        Builder b(boxes, 0, hs->items.size());
         b.nodes.reserve(boxes.size());
         b.order.reserve(boxes.size());
-        *root = b.build(0, boxes.size(), bound, 0);
-        if (b.max_depth + 2 > BVH_STACK) return fail(err, PTR_ERR_LIMIT, "BVH deeper than the traversal stack");
-        if (b.max_depth > hs->bvh_depth) hs->bvh_depth = b.max_depth;
-        hs->nodes.insert(hs->nodes.end(), b.nodes.begin(), b.nodes.end());
+        const int32_t root2 = b.build(0, boxes.size(), bound, 0);
+        Collapser c(b.nodes, hs->nodes);
+        *root = c.emit(root2, 0);
+        /* per lane: up to three pushed siblings per level of this tree, on top of the top-level walk's entries
+         * (the persistent tracer keeps both in one stack; the reference's top tree is at most 20 deep) */
+        if (3 * (c.max_depth + 1) + 24 > BVH_STACK) return fail(err, PTR_ERR_LIMIT, "BVH deeper than the traversal stack");
+        if (c.max_depth > hs->bvh_depth) hs->bvh_depth = c.max_depth;
         for (size_t i = 0; i < b.order.size(); i++) hs->items.push_back(raw[b.order[i]]);
         return PTR_OK;
     };

@@ -30,7 +30,7 @@ struct HostTable { /* BSSRDFTable, bssrdf.h:29-42 */
     std::vector<float> rho, radius, profile, rho_eff, profile_cdf;
 };
 struct HostScene {
-    std::vector<Node64> nodes;
+    std::vector<Node128> nodes;
     std::vector<Item48> items;
     std::vector<DPrim> prims;
     std::vector<DMat> mats;

@@ -677,7 +677,7 @@ int ptr_scene_upload(PtrContext *ctx, const PtrFlatScene *scene) {
     sc.view_medium = hs.view_medium;
     sc.has_env = hs.has_env;
     ctx->sc = sc;
-    ctx->bvh_bytes = (int64_t)(hs.nodes.size() * sizeof(Node64) + hs.items.size() * sizeof(Item48));
+    ctx->bvh_bytes = (int64_t)(hs.nodes.size() * sizeof(Node128) + hs.items.size() * sizeof(Item48));
     ctx->scene_has_media = hs.has_media;
     ctx->scene_has_sss = !hs.tables.empty();
     ctx->scene_all_opaque = true;

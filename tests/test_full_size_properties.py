@@ -31,7 +31,7 @@ def test_bvh_shape(big):
     info = r.bvh_info()
     assert info["items"] == 871200  # every triangle exactly once (analytic primitives are not BVH items)
     assert info["nodes"] < info["items"]
-    assert info["bytes"] == 64 * info["nodes"] + 48 * info["items"]
+    assert info["bytes"] == 128 * info["nodes"] + 48 * info["items"]
 
 
 def test_closest_vs_occluded_consistency(big):
