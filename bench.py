@@ -165,14 +165,14 @@ def main():
     dt_max, rays_all, cam_all = [float(v) for v in stats.cpu()]
 
     if rank == 0:
-        tk = prof["trace_closest"]
+        tk = prof["trace_closest"]  # closest-hit launches of the persistent tracer over the path segments
         traced = max(1, cc["total_paths"])
         nodes_per_ray = cc["nodes_visited"] / traced
         items_per_ray = cc["prims_tested"] / traced
         bytes_per_ray = 64.0 + 32.0 * nodes_per_ray + 48.0 * items_per_ray
         launches = max(1, tk["launches"])
         avg_ms = tk["total_ms"] / launches
-        rays_per_launch = c["total_paths"] / launches  # every path segment is one ray of this kernel
+        rays_per_launch = c["total_paths"] / launches  # every path segment is one ray of this kernel (incl. the few per cent the finish kernel traces itself)
         achieved = bytes_per_ray * rays_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic, traffic_src = measured_traffic("k_ptrace<false, false>")
         out = {
@@ -197,7 +197,7 @@ def main():
                        "scene_upload_s": round(t_up, 3), "parallelism": "samples round-robin over %d GPU(s), scene replicated" % world},
             "samples_per_s": cam_all / dt_max,
             "rays_per_sample": rays_all / max(1.0, cam_all),
-            "roofline": {"bound": "hbm", "kernel": "k_ptrace<false, false> (closest hit)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_ptrace<false,false> (persistent tracer, closest hit)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": bytes_per_ray * rays_per_launch,
                          "bytes_per_ray": bytes_per_ray, "nodes_per_ray": nodes_per_ray, "items_per_ray": items_per_ray,

@@ -50,13 +50,85 @@ enum { TM_IDLE = 0, TM_TOP = 1, TM_TOPLEAF = 2, TM_GEOM = 3 };
 #define PT_REFILL 24
 #endif
 
-template <bool ANY, bool COUNT>
-PD void persistent_trace(const DScene &sc, const TraceIO &io, int *lds, unsigned *total_nodes, unsigned *total_items) {
+PD void trace_io_fetch(const TraceIO &io, int idx, int *slot, f3 *ro, f3 *rd, float *tmax) {
+    const int s = io.queue ? io.queue[idx] : idx;
+    const char *po = io.o + (long long)s * io.o_es;
+    const char *pd = io.d + (long long)s * io.d_es;
+    *ro = f3(*(const float *)po, *(const float *)(po + io.o_cs), *(const float *)(po + 2 * io.o_cs));
+    *rd = f3(*(const float *)pd, *(const float *)(pd + io.d_cs), *(const float *)(pd + 2 * io.d_cs));
+    *tmax = io.tmax ? *(const float *)(io.tmax + (long long)s * io.tmax_es) : io.tmax_const;
+    *slot = s;
+}
+template <bool COUNT>
+PD void trace_io_store(const TraceIO &io, bool any, int slot, bool hit, int hp, int hf, float tmax, float hb0, float hb1, unsigned rn, unsigned ri) {
+    if (any) {
+        if (io.prim) *(int *)(io.prim + (long long)slot * io.prim_es) = hit ? 1 : 0;
+        return;
+    }
+    if (io.prim) *(int *)(io.prim + (long long)slot * io.prim_es) = hit ? hp : -1;
+    if (io.face) *(int *)(io.face + (long long)slot * io.face_es) = hit ? hf : -1;
+    if (io.t) *(float *)(io.t + (long long)slot * io.t_es) = tmax;
+    if (COUNT && io.b0 && io.b1) {
+        *(float *)(io.b0 + (long long)slot * io.b0_es) = (float)rn;
+        *(float *)(io.b1 + (long long)slot * io.b1_es) = (float)ri;
+    } else {
+        if (io.b0) *(float *)(io.b0 + (long long)slot * io.b0_es) = hit ? hb0 : 0;
+        if (io.b1) *(float *)(io.b1 + (long long)slot * io.b1_es) = hit ? hb1 : 0;
+    }
+}
+
+/* Where the rays of a launch come from.  OneSource: one queue, all closest-hit or all any-hit
+ * (known at compile time).  ThreeSources: the three queues a bounce produces - next path segments
+ * (closest hit), shadow rays (any hit), MIS rays (closest hit) - served by ONE launch: a launch
+ * lasts about as long as its longest ray, so three launches per bounce pay that tail three times
+ * and run their last waves on a mostly empty GPU. */
+template <bool ANY>
+struct OneSource {
+    TraceIO io;
+    int n_rays;
+    int *counter;
+    PD void init() { n_rays = io.n_ptr ? *io.n_ptr : io.n; counter = io.counter; }
+    PD int total() const { return n_rays; }
+    PD bool is_any(int) const { return ANY; }
+    PD void fetch(int idx, int *tag, int *slot, f3 *ro, f3 *rd, float *tmax) const { *tag = 0; trace_io_fetch(io, idx, slot, ro, rd, tmax); }
+    template <bool COUNT>
+    PD void store(int, int slot, bool hit, int hp, int hf, float tmax, float hb0, float hb1, unsigned rn, unsigned ri) const {
+        trace_io_store<COUNT>(io, ANY, slot, hit, hp, hf, tmax, hb0, hb1, rn, ri);
+    }
+};
+struct ThreeSources {
+    TraceIO path, shadow, mis; /* path.counter is the fetch cursor of the launch */
+    int n0, n01, n012;
+    int *counter;
+    PD void init() {
+        n0 = path.n_ptr ? *path.n_ptr : path.n;
+        n01 = n0 + (shadow.n_ptr ? *shadow.n_ptr : shadow.n);
+        n012 = n01 + (mis.n_ptr ? *mis.n_ptr : mis.n);
+        counter = path.counter;
+    }
+    PD int total() const { return n012; }
+    PD bool is_any(int tag) const { return tag == 1; }
+    PD void fetch(int idx, int *tag, int *slot, f3 *ro, f3 *rd, float *tmax) const {
+        if (idx < n0) { *tag = 0; trace_io_fetch(path, idx, slot, ro, rd, tmax); }
+        else if (idx < n01) { *tag = 1; trace_io_fetch(shadow, idx - n0, slot, ro, rd, tmax); }
+        else { *tag = 2; trace_io_fetch(mis, idx - n01, slot, ro, rd, tmax); }
+    }
+    template <bool COUNT>
+    PD void store(int tag, int slot, bool hit, int hp, int hf, float tmax, float hb0, float hb1, unsigned rn, unsigned ri) const {
+        if (tag == 0) trace_io_store<COUNT>(path, false, slot, hit, hp, hf, tmax, hb0, hb1, rn, ri);
+        else if (tag == 1) trace_io_store<COUNT>(shadow, true, slot, hit, hp, hf, tmax, hb0, hb1, rn, ri);
+        else trace_io_store<COUNT>(mis, false, slot, hit, hp, hf, tmax, hb0, hb1, rn, ri);
+    }
+};
+
+template <class Source, bool COUNT>
+PD void persistent_trace(const DScene &sc, Source src, int *lds, unsigned *total_nodes, unsigned *total_items) {
     int ovf[OVF_STACK];
     const int lane = __lane_id();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
-    int mode = TM_IDLE, slot = -1;
+    int mode = TM_IDLE, slot = -1, tag = 0;
+    src.init();
     f3 ro, rd, inv;
     TriRay tr;
     tr.kx = tr.ky = tr.kz = 0; tr.Sx = tr.Sy = tr.Sz = 0;
@@ -66,30 +138,18 @@ PD void persistent_trace(const DScene &sc, const TraceIO &io, int *lds, unsigned
     int tnode = -1, leaf_pos = 0, leaf_end = 0, cp = -1, node = 0, sp = 0, sp_base = 0;
     unsigned rn = 0, ri = 0; /* per-ray work (COUNT) */
 
-    const int n_rays = io.n_ptr ? *io.n_ptr : io.n;
+    const int n_rays = src.total();
     int pool_pos = 0, pool_end = 0; /* wave-uniform */
     bool exhausted = false;
 
-#define PT_FINISH()                                                                             \
-    do {                                                                                        \
-        if (ANY) {                                                                              \
-            if (io.prim) *(int *)(io.prim + (long long)slot * io.prim_es) = hit ? 1 : 0;        \
-        } else {                                                                                \
-            if (io.prim) *(int *)(io.prim + (long long)slot * io.prim_es) = hit ? hp : -1;      \
-            if (io.face) *(int *)(io.face + (long long)slot * io.face_es) = hit ? hf : -1;      \
-            if (io.t) *(float *)(io.t + (long long)slot * io.t_es) = tmax;                      \
-            if (COUNT && io.b0 && io.b1) {                                                      \
-                *(float *)(io.b0 + (long long)slot * io.b0_es) = (float)rn;                     \
-                *(float *)(io.b1 + (long long)slot * io.b1_es) = (float)ri;                     \
-            } else {                                                                            \
-                if (io.b0) *(float *)(io.b0 + (long long)slot * io.b0_es) = hit ? hb0 : 0;      \
-                if (io.b1) *(float *)(io.b1 + (long long)slot * io.b1_es) = hit ? hb1 : 0;      \
-            }                                                                                   \
-        }                                                                                       \
-        if (COUNT) { *total_nodes += rn; *total_items += ri; }                                  \
-        mode = TM_IDLE;                                                                         \
-        slot = -1;                                                                              \
+#define PT_FINISH()                                                                  \
+    do {                                                                             \
+        src.template store<COUNT>(tag, slot, hit, hp, hf, tmax, hb0, hb1, rn, ri);   \
+        if (COUNT) { *total_nodes += rn; *total_items += ri; }                       \
+        mode = TM_IDLE;                                                              \
+        slot = -1;                                                                   \
     } while (0)
+#define PT_ANY (src.is_any(tag))
 
     for (;;) {
         /* ---- refill idle lanes ---- */
@@ -99,7 +159,7 @@ PD void persistent_trace(const DScene &sc, const TraceIO &io, int *lds, unsigned
         if (idle && (__popcll(idle) >= PT_REFILL || __ballot(mode == TM_GEOM) == 0)) {
             if (pool_pos >= pool_end && !exhausted) {
                 int base = 0;
-                if (lane == 0) base = atomicAdd(io.counter, 64);
+                if (lane == 0) base = atomicAdd(src.counter, 64);
                 base = __shfl(base, 0, 64);
                 if (base >= n_rays) exhausted = true;
                 else {
@@ -112,12 +172,7 @@ PD void persistent_trace(const DScene &sc, const TraceIO &io, int *lds, unsigned
                 const int rank = __popcll(idle & lt_mask);
                 if (mode == TM_IDLE && rank < avail) {
                     const int idx = pool_pos + rank;
-                    slot = io.queue ? io.queue[idx] : idx;
-                    const char *po = io.o + (long long)slot * io.o_es;
-                    const char *pd = io.d + (long long)slot * io.d_es;
-                    ro = f3(*(const float *)po, *(const float *)(po + io.o_cs), *(const float *)(po + 2 * io.o_cs));
-                    rd = f3(*(const float *)pd, *(const float *)(pd + io.d_cs), *(const float *)(pd + 2 * io.d_cs));
-                    tmax = io.tmax ? *(const float *)(io.tmax + (long long)slot * io.tmax_es) : io.tmax_const;
+                    src.fetch(idx, &tag, &slot, &ro, &rd, &tmax);
                     inv = f3(1 / rd.x, 1 / rd.y, 1 / rd.z);
                     tr = tri_ray_setup(rd);
                     hp = -1; hf = -1; hb0 = 0; hb1 = 0; hit = false;
@@ -184,7 +239,7 @@ PD void persistent_trace(const DScene &sc, const TraceIO &io, int *lds, unsigned
                         if (COUNT) ri += 1;
                         if (shape_hit_t(sc, pr, ro, rd, tmax, &t, &face)) {
                             tmax = t; hp = p; hf = face; hb0 = 0; hb1 = 0; hit = true;
-                            if (ANY) { PT_FINISH(); break; }
+                            if (PT_ANY) { PT_FINISH(); break; }
                         }
                     }
                 }
@@ -221,7 +276,7 @@ PD void persistent_trace(const DScene &sc, const TraceIO &io, int *lds, unsigned
                     float t, b0, b1, b2;
                     if (tri_hit_pre(ro, tr, tmax, f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), &t, &b0, &b1, &b2)) {
                         tmax = t; hp = cp; hf = __float_as_int(q1.w); hb0 = b0; hb1 = b1; hit = true;
-                        if (ANY) { ended = true; break; }
+                        if (PT_ANY) { ended = true; break; }
                     }
                 } else {
                     f3 o, dd;
@@ -229,7 +284,7 @@ PD void persistent_trace(const DScene &sc, const TraceIO &io, int *lds, unsigned
                     float t;
                     if (sphere_hit_t_obj(o, dd, q1.x, tmax, &t)) {
                         tmax = t; hp = cp; hf = __float_as_int(q1.w); hb0 = 0; hb1 = 0; hit = true;
-                        if (ANY) { ended = true; break; }
+                        if (PT_ANY) { ended = true; break; }
                     }
                 }
             }
@@ -239,4 +294,5 @@ PD void persistent_trace(const DScene &sc, const TraceIO &io, int *lds, unsigned
         }
     }
 #undef PT_FINISH
+#undef PT_ANY
 }

@@ -224,6 +224,9 @@ struct PtrContext {
     DScene sc;
     bool has_scene = false, has_camera = false, has_film = false;
     bool scene_has_media = false, scene_all_opaque = false, scene_passthrough = false;
+    /* one tracer launch per bounce for {next segments, shadow rays, MIS rays} instead of three: 6 % less GPU
+     * time for a pass that has the GPU to itself, 2 % more when four passes overlap (bench.py): off by default */
+    bool merge_traces = false;
     bool scene_has_sss = false; /* some material carries a BSSRDF: k_shade<true> / k_finish<true> */
     DCamera cam;
     int64_t bvh_bytes = 0;
@@ -371,23 +374,48 @@ static int api_trace(PtrContext *ctx, TraceIO io, bool any) {
     return PTR_OK;
 }
 
-/* One bounce of a pass on a lane: trace the live paths, shade them, trace and sum their
- * direct-light records.  n_ptr / n_host: number of live paths (device counter of the previous
- * bounce, or a host value); n_upper: an upper bound used only to size grids; cslot: which
- * [4]+[3] counter block of the lane this bounce writes (must be zero). */
-static void enqueue_bounce(PtrContext *ctx, Lane &l, const PassParams &prm, const int *n_ptr, int n_host, int n_upper, const int *q_cur,
-                           int *q_next, int cslot) {
+/* The stages of one bounce on a lane.  Counter block `cslot` of the lane ([0] live paths after
+ * the bounce, [1] direct-light records, [2] shadow rays, [3] MIS rays) and its fetch cursors must
+ * be zero; n_ptr / n_host: number of live paths entering the bounce (device counter of the
+ * previous bounce, or a host value); n_upper: an upper bound used only to size grids. */
+static TraceIO path_io(const Lane &l, const int *queue, const int *n_ptr, int n_host, int *cursor) {
+    TraceIO io = soa_io(n_host, queue, l.pipe.cap, l.pipe.ro, l.pipe.rd, nullptr, l.pipe.hprim, l.pipe.hface, l.pipe.ht, nullptr, nullptr);
+    io.n_ptr = n_ptr;
+    io.counter = cursor;
+    return io;
+}
+static TraceIO shadow_io(const Lane &l, const int *queue, const int *n_ptr, int *cursor) { /* any hit within (0, 1 - ShadowEpsilon) */
+    const char *nee = (const char *)l.pipe.nee;
+    const long long plane = 4ll * l.pipe.cap; /* bytes between the planes of consecutive words */
+    TraceIO io;
+    memset(&io, 0, sizeof(io));
+    io.queue = queue; io.n_ptr = n_ptr;
+    io.o = nee + WORD_OF(NeeRec, oA) * plane; io.o_es = 4; io.o_cs = plane;
+    io.d = nee + WORD_OF(NeeRec, dA) * plane; io.d_es = 4; io.d_cs = plane;
+    io.tmax_const = 1 - 0.0001f;
+    io.prim = (char *)nee + WORD_OF(NeeRec, occA) * plane; io.prim_es = 4;
+    io.counter = cursor;
+    return io;
+}
+static TraceIO mis_io(const Lane &l, const int *queue, const int *n_ptr, int *cursor) { /* closest hit */
+    const char *nee = (const char *)l.pipe.nee;
+    const long long plane = 4ll * l.pipe.cap;
+    TraceIO io;
+    memset(&io, 0, sizeof(io));
+    io.queue = queue; io.n_ptr = n_ptr;
+    io.o = nee + WORD_OF(NeeRec, oB) * plane; io.o_es = 4; io.o_cs = plane;
+    io.d = nee + WORD_OF(NeeRec, dB) * plane; io.d_es = 4; io.d_cs = plane;
+    io.tmax_const = FLT_MAX;
+    io.prim = (char *)nee + WORD_OF(NeeRec, hitB) * plane; io.prim_es = 4;
+    io.t = (char *)nee + WORD_OF(NeeRec, tB) * plane; io.t_es = 4;
+    io.counter = cursor;
+    return io;
+}
+static void enqueue_shade(PtrContext *ctx, Lane &l, const PassParams &prm, const int *n_ptr, int n_host, int n_upper, const int *q_cur, int *q_next,
+                          int cslot) {
     hipStream_t s = l.stream;
-    int *q_nee = l.queues[2], *q_shadow = l.queues[3], *q_mis = l.queues[4];
     int *cnt = l.counts + 4 * cslot;
-    int *fetch = l.counts + 4 * MAX_ITERS + 3 * cslot;
     const unsigned stride_blocks = clampu(nblocks(n_upper), 32, 2048);
-    {
-        TraceIO io = soa_io(n_host, q_cur, l.pipe.cap, l.pipe.ro, l.pipe.rd, nullptr, l.pipe.hprim, l.pipe.hface, l.pipe.ht, nullptr, nullptr);
-        io.n_ptr = n_ptr;
-        io.counter = fetch + 0;
-        launch_ptrace(ctx, s, io, n_upper, false, ctx->count_traversal, K_TRACE);
-    }
     const int *q_shade = q_cur;
     if (ctx->bin_by_material) {
         int *cls = l.counts + 7 * MAX_ITERS + 2 * N_CLASSES * cslot;
@@ -397,56 +425,33 @@ static void enqueue_bounce(PtrContext *ctx, Lane &l, const PassParams &prm, cons
                            cls + N_CLASSES, l.queues[5]);
         q_shade = l.queues[5];
     }
+    ProfScope ps(ctx, s, K_SHADE, (uint64_t)(n_ptr ? 0 : n_host));
+    const int walk_i = prm.integrator == PTR_LI_VOLPATH && !ctx->scene_all_opaque ? 1 : 0;
+    const ShadeArgs a = {ctx->sc, l.pipe, prm, n_ptr, n_host, q_shade, q_next, l.queues[2], l.queues[3], l.queues[4], cnt, walk_i, ctx->ctrs};
+    if (ctx->scene_has_sss) rt_launch_shade_sss(stride_blocks, s, a);
+    else rt_launch_shade(stride_blocks, s, a);
+}
+/* direct light of the bounce when a shadow / MIS ray may pass through primitives (Li_VolPath with
+ * medium boundaries or emitters): the walks of VisibilityTester::Tr / IntersectTr run in-kernel */
+static void enqueue_nee_walks(PtrContext *ctx, Lane &l, int n_upper, int cslot) {
+    hipStream_t s = l.stream;
+    int *cnt = l.counts + 4 * cslot;
+    const unsigned stride_blocks = clampu(nblocks(n_upper), 32, 2048);
     {
-        ProfScope ps(ctx, s, K_SHADE, (uint64_t)(n_ptr ? 0 : n_host));
-        const int walk_i = prm.integrator == PTR_LI_VOLPATH && !ctx->scene_all_opaque ? 1 : 0;
-        const ShadeArgs a = {ctx->sc, l.pipe, prm, n_ptr, n_host, q_shade, q_next, q_nee, q_shadow, q_mis, cnt, walk_i, ctx->ctrs};
-        if (ctx->scene_has_sss) rt_launch_shade_sss(stride_blocks, s, a);
-        else rt_launch_shade(stride_blocks, s, a);
+        ProfScope ps(ctx, s, K_SHADOW, 0);
+        rt_launch_shadow_walk(stride_blocks, s, ctx->sc, l.pipe, (const int *)(cnt + 2), 0, (const int *)l.queues[3], ctx->ctrs);
     }
-    /* the walks of VisibilityTester::Tr / IntersectTr can only go past their first hit under
-     * Li_VolPath and only if some primitive has no material (medium boundary, emitter) */
-    const bool walk = prm.integrator == PTR_LI_VOLPATH && !ctx->scene_all_opaque;
-    if (walk) {
-        {
-            ProfScope ps(ctx, s, K_SHADOW, 0);
-            rt_launch_shadow_walk(stride_blocks, s, ctx->sc, l.pipe, (const int *)(cnt + 2), 0, (const int *)q_shadow, ctx->ctrs);
-        }
-        {
-            ProfScope ps(ctx, s, K_MIS, 0);
-            rt_launch_mis_walk(stride_blocks, s, ctx->sc, l.pipe, (const int *)(cnt + 1), 0, (const int *)q_nee, ctx->ctrs);
-        }
-    } else {
-        const char *nee = (const char *)l.pipe.nee;
-        const long long plane = 4ll * l.pipe.cap; /* bytes between the planes of consecutive words */
-        { /* shadow rays: any hit within (0, 1 - ShadowEpsilon) */
-            TraceIO io;
-            memset(&io, 0, sizeof(io));
-            io.queue = q_shadow; io.n_ptr = cnt + 2;
-            io.o = nee + WORD_OF(NeeRec, oA) * plane; io.o_es = 4; io.o_cs = plane;
-            io.d = nee + WORD_OF(NeeRec, dA) * plane; io.d_es = 4; io.d_cs = plane;
-            io.tmax_const = 1 - 0.0001f;
-            io.prim = (char *)nee + WORD_OF(NeeRec, occA) * plane; io.prim_es = 4;
-            io.counter = fetch + 1;
-            launch_ptrace(ctx, s, io, n_upper, true, false, K_SHADOW);
-        }
-        { /* MIS rays: closest hit */
-            TraceIO io;
-            memset(&io, 0, sizeof(io));
-            io.queue = q_mis; io.n_ptr = cnt + 3;
-            io.o = nee + WORD_OF(NeeRec, oB) * plane; io.o_es = 4; io.o_cs = plane;
-            io.d = nee + WORD_OF(NeeRec, dB) * plane; io.d_es = 4; io.d_cs = plane;
-            io.tmax_const = FLT_MAX;
-            io.prim = (char *)nee + WORD_OF(NeeRec, hitB) * plane; io.prim_es = 4;
-            io.t = (char *)nee + WORD_OF(NeeRec, tB) * plane; io.t_es = 4;
-            io.counter = fetch + 2;
-            launch_ptrace(ctx, s, io, n_upper, false, false, K_MIS);
-        }
-        {
-            ProfScope ps(ctx, s, K_RESOLVE, 0);
-            hipLaunchKernelGGL(k_nee_resolve, dim3(stride_blocks), dim3(TPB), 0, s, ctx->sc, l.pipe, (const int *)(cnt + 1), 0, (const int *)q_nee, ctx->ctrs);
-        }
+    {
+        ProfScope ps(ctx, s, K_MIS, 0);
+        rt_launch_mis_walk(stride_blocks, s, ctx->sc, l.pipe, (const int *)(cnt + 1), 0, (const int *)l.queues[2], ctx->ctrs);
     }
+}
+static void enqueue_resolve(PtrContext *ctx, Lane &l, int n_upper, int cslot) {
+    hipStream_t s = l.stream;
+    int *cnt = l.counts + 4 * cslot;
+    ProfScope ps(ctx, s, K_RESOLVE, 0);
+    hipLaunchKernelGGL(k_nee_resolve, dim3(clampu(nblocks(n_upper), 32, 2048)), dim3(TPB), 0, s, ctx->sc, l.pipe, (const int *)(cnt + 1), 0,
+                       (const int *)l.queues[2], ctx->ctrs);
 }
 
 /* one pass on a lane: nb samples (first, first+step, ...) of every pixel */
@@ -489,13 +494,47 @@ static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int ste
     if (staged > MAX_ITERS) staged = MAX_ITERS;
     const int *q_cur = nullptr; /* identity */
     int qi = 0;
-    for (int k = 0; k < staged; k++) {
-        int *q_next = l.queues[qi];
-        int upper = slots >> (k < 6 ? k : 6);
-        if (upper < 1) upper = 1;
-        enqueue_bounce(ctx, l, prm, k == 0 ? nullptr : l.counts + 4 * (k - 1), slots, k == 0 ? slots : upper, q_cur, q_next, k);
-        q_cur = q_next;
-        qi ^= 1;
+    /* the walks of VisibilityTester::Tr / IntersectTr can only go past their first hit under
+     * Li_VolPath and only if some primitive has no material (medium boundary, emitter) */
+    const bool walks = integrator == PTR_LI_VOLPATH && !ctx->scene_all_opaque;
+    int *cursors = l.counts + 4 * MAX_ITERS; /* ray-fetch cursors of the trace launches, 3 per bounce */
+    auto upper_at = [&](int k) { int u = slots >> (k < 6 ? k : 6); return u < 1 ? 1 : u; };
+    if (!walks && ctx->merge_traces) {
+        /* per bounce: shade, then ONE trace launch for the rays it made - the next path segments, the
+         * shadow rays and the MIS rays - then the direct-light sum (before the next shade adds emission) */
+        launch_ptrace(ctx, s, path_io(l, nullptr, nullptr, slots, cursors + 0), slots, false, ctx->count_traversal, K_TRACE);
+        for (int k = 0; k < staged; k++) {
+            int *q_next = l.queues[qi];
+            int *cnt = l.counts + 4 * k;
+            enqueue_shade(ctx, l, prm, k == 0 ? nullptr : l.counts + 4 * (k - 1), slots, upper_at(k), q_cur, q_next, k);
+            const bool more = k + 1 < staged; /* after the last staged bounce the finish kernel traces the survivors itself */
+            TraceIO p = path_io(l, q_next, more ? cnt + 0 : nullptr, 0, cursors + 3 * k + 1);
+            const int n_upper = (more ? upper_at(k + 1) : 0) + 2 * upper_at(k);
+            {
+                ProfScope ps(ctx, s, K_TRACE, 0);
+                rt_launch_ptrace3(ctx->count_traversal, clampu(nblocks(n_upper), 1, (unsigned)ctx->persist_blocks), s, ctx->sc, p,
+                                  shadow_io(l, l.queues[3], cnt + 2, nullptr), mis_io(l, l.queues[4], cnt + 3, nullptr), ctx->ctrs);
+            }
+            enqueue_resolve(ctx, l, upper_at(k), k);
+            q_cur = q_next;
+            qi ^= 1;
+        }
+    } else {
+        for (int k = 0; k < staged; k++) {
+            int *q_next = l.queues[qi];
+            const int *n_ptr = k == 0 ? nullptr : l.counts + 4 * (k - 1);
+            launch_ptrace(ctx, s, path_io(l, q_cur, n_ptr, slots, cursors + 3 * k), upper_at(k), false, ctx->count_traversal, K_TRACE);
+            enqueue_shade(ctx, l, prm, n_ptr, slots, upper_at(k), q_cur, q_next, k);
+            if (walks) enqueue_nee_walks(ctx, l, upper_at(k), k);
+            else { /* a launch per ray kind */
+                int *cnt = l.counts + 4 * k;
+                launch_ptrace(ctx, s, shadow_io(l, l.queues[3], cnt + 2, cursors + 3 * k + 1), upper_at(k), true, false, K_SHADOW);
+                launch_ptrace(ctx, s, mis_io(l, l.queues[4], cnt + 3, cursors + 3 * k + 2), upper_at(k), false, false, K_MIS);
+                enqueue_resolve(ctx, l, upper_at(k), k);
+            }
+            q_cur = q_next;
+            qi ^= 1;
+        }
     }
     if (integrator != PTR_LI_DIRECT) {
         const bool walk = integrator == PTR_LI_VOLPATH && !ctx->scene_all_opaque;
@@ -565,6 +604,7 @@ int ptr_create(int device, PtrContext **out) {
         int v = atoi(e);
         if (v > 0) { ctx->staged_bounces = v; ctx->staged_fixed = true; }
     }
+    if (const char *e = getenv("PTR_MERGE")) ctx->merge_traces = atoi(e) != 0; /* tuning experiments */
     if (const char *e = getenv("PTR_BIN")) ctx->bin_by_material = atoi(e) != 0; /* tuning experiments */
     if (const char *e = getenv("PTR_SPREAD")) { /* tuning experiments */
         int v = atoi(e);

@@ -9,13 +9,37 @@ template <bool ANY, bool COUNT>
 __global__ void __launch_bounds__(TRACE_TPB) __attribute__((amdgpu_waves_per_eu(PT_WAVES, PT_WAVES))) k_ptrace(DScene sc, TraceIO io, unsigned long long *ctrs) {
     __shared__ int s_stack[LDS_STACK * TRACE_TPB];
     unsigned tn = 0, ti = 0;
-    persistent_trace<ANY, COUNT>(sc, io, &s_stack[threadIdx.x], &tn, &ti);
+    OneSource<ANY> src;
+    src.io = io;
+    persistent_trace<OneSource<ANY>, COUNT>(sc, src, &s_stack[threadIdx.x], &tn, &ti);
     if (COUNT) {
         ctr_flush(ctrs, C_NODES, tn);
         ctr_flush(ctrs, C_PRIMS, ti);
     }
 }
 
+/* the three ray queues of one bounce - next path segments, shadow rays, MIS rays - in one launch */
+template <bool COUNT>
+__global__ void __launch_bounds__(TRACE_TPB) __attribute__((amdgpu_waves_per_eu(PT_WAVES, PT_WAVES)))
+k_ptrace3(DScene sc, TraceIO path, TraceIO shadow, TraceIO mis, unsigned long long *ctrs) {
+    __shared__ int s_stack[LDS_STACK * TRACE_TPB];
+    unsigned tn = 0, ti = 0;
+    ThreeSources src;
+    src.path = path;
+    src.shadow = shadow;
+    src.mis = mis;
+    persistent_trace<ThreeSources, COUNT>(sc, src, &s_stack[threadIdx.x], &tn, &ti);
+    if (COUNT) {
+        ctr_flush(ctrs, C_NODES, tn);
+        ctr_flush(ctrs, C_PRIMS, ti);
+    }
+}
+
+void rt_launch_ptrace3(bool count, unsigned blocks, hipStream_t s, const DScene &sc, const TraceIO &path, const TraceIO &shadow, const TraceIO &mis,
+                       unsigned long long *ctrs) {
+    if (count) hipLaunchKernelGGL((k_ptrace3<true>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, path, shadow, mis, ctrs);
+    else hipLaunchKernelGGL((k_ptrace3<false>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, path, shadow, mis, ctrs);
+}
 
 void rt_launch_ptrace(bool any, bool count, unsigned blocks, hipStream_t s, const DScene &sc, const TraceIO &io, unsigned long long *ctrs) {
     if (any) hipLaunchKernelGGL((k_ptrace<true, false>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, io, ctrs);
