@@ -490,6 +490,7 @@ static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int ste
      * whatever is there. */
     const int max_iters = integrator == PTR_LI_DIRECT ? 1 : integrator == PTR_LI_PATH ? 10 : integrator == PTR_LI_PATHSAMPLED ? 11 : 16;
     int staged = ctx->staged_bounces < max_iters ? ctx->staged_bounces : max_iters;
+    if (ctx->count_traversal) staged = max_iters; /* counting passes: every ray goes through the tracer's counting variant, none through k_finish */
     if (staged < 1) staged = 1;
     if (staged > MAX_ITERS) staged = MAX_ITERS;
     const int *q_cur = nullptr; /* identity */
@@ -529,7 +530,7 @@ static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int ste
             else { /* a launch per ray kind */
                 int *cnt = l.counts + 4 * k;
                 launch_ptrace(ctx, s, shadow_io(l, l.queues[3], cnt + 2, cursors + 3 * k + 1), upper_at(k), true, false, K_SHADOW);
-                launch_ptrace(ctx, s, mis_io(l, l.queues[4], cnt + 3, cursors + 3 * k + 2), upper_at(k), false, false, K_MIS);
+                launch_ptrace(ctx, s, mis_io(l, l.queues[4], cnt + 3, cursors + 3 * k + 2), upper_at(k), false, ctx->count_traversal, K_MIS);
                 enqueue_resolve(ctx, l, upper_at(k), k);
             }
             q_cur = q_next;
