@@ -53,21 +53,45 @@ PD bool slab_test(const float *bmin, const float *bmax, const f3 &o, const f3 &i
     return true;
 }
 
-/* the same test on a box given by scalars (a child slot of a 4-wide node) */
+/* The same test on a box given by scalars (a child slot of a 4-wide node), without the early
+ * exits: the entry bound only grows and the exit bound only shrinks from axis to axis, so "t0 > t1
+ * after some axis" and "t0 > t1 after the last axis" are the same predicate (NaNs from 0 * inf leave
+ * both bounds untouched in either form).  Straight-line code: no EXEC-mask juggling per axis, and
+ * the four children of a node interleave. */
 PD bool slab_test6(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, const f3 &o, const f3 &inv, float tmax, float *t_entry) {
-    const float bmin[3] = {mnx, mny, mnz}, bmax[3] = {mxx, mxy, mxz};
-    return slab_test(bmin, bmax, o, inv, tmax, t_entry);
+    const float k = 1 + 2 * gammar(3);
+    float t0 = 0, t1 = tmax;
+    {
+        float tn = (mnx - o.x) * inv.x, tf = (mxx - o.x) * inv.x;
+        const float lo = tn > tf ? tf : tn, hi = (tn > tf ? tn : tf) * k;
+        t0 = lo > t0 ? lo : t0;
+        t1 = hi < t1 ? hi : t1;
+    }
+    {
+        float tn = (mny - o.y) * inv.y, tf = (mxy - o.y) * inv.y;
+        const float lo = tn > tf ? tf : tn, hi = (tn > tf ? tn : tf) * k;
+        t0 = lo > t0 ? lo : t0;
+        t1 = hi < t1 ? hi : t1;
+    }
+    {
+        float tn = (mnz - o.z) * inv.z, tf = (mxz - o.z) * inv.z;
+        const float lo = tn > tf ? tf : tn, hi = (tn > tf ? tn : tf) * k;
+        t0 = lo > t0 ? lo : t0;
+        t1 = hi < t1 ? hi : t1;
+    }
+    *t_entry = t0;
+    return !(t0 > t1);
 }
 
 /* One visit of a 4-wide node (dev_scene.h Node128): tests the occupied child slots and leaves the
  * refs of those the ray enters in r0..r3, nearest first (BVH_NO_CHILD pads the tail).  A sorting
  * network over (entry distance, ref) pairs keeps everything in registers. */
-#define BVH4_CSWAP(ta, ra, tb, rb)      \
-    do {                                \
-        if (tb < ta) {                  \
-            float ts_ = ta; ta = tb; tb = ts_; \
-            int rs_ = ra; ra = rb; rb = rs_;   \
-        }                               \
+#define BVH4_CSWAP(ta, ra, tb, rb)                       \
+    do {                                                 \
+        const bool sw_ = tb < ta;                        \
+        const float tl_ = sw_ ? tb : ta, th_ = sw_ ? ta : tb; \
+        const int rl_ = sw_ ? rb : ra, rh_ = sw_ ? ra : rb;   \
+        ta = tl_; tb = th_; ra = rl_; rb = rh_;          \
     } while (0)
 PD int bvh4_visit(const Node128 *nodes, int node, const f3 &ro, const f3 &inv, float tmax, int &r0, int &r1, int &r2, int &r3, unsigned *tested) {
     const float4 *np = reinterpret_cast<const float4 *>(nodes + node);
@@ -76,10 +100,16 @@ PD int bvh4_visit(const Node128 *nodes, int node, const f3 &ro, const f3 &inv, f
     r0 = __float_as_int(chf.x); r1 = __float_as_int(chf.y); r2 = __float_as_int(chf.z); r3 = __float_as_int(chf.w);
     float t0 = kInfinity, t1 = kInfinity, t2 = kInfinity, t3 = kInfinity;
     if (tested) *tested += (r0 != BVH_NO_CHILD) + (r1 != BVH_NO_CHILD) + (r2 != BVH_NO_CHILD) + (r3 != BVH_NO_CHILD);
-    if (!(r0 != BVH_NO_CHILD && slab_test6(mnx.x, mny.x, mnz.x, mxx.x, mxy.x, mxz.x, ro, inv, tmax, &t0))) { r0 = BVH_NO_CHILD; t0 = kInfinity; }
-    if (!(r1 != BVH_NO_CHILD && slab_test6(mnx.y, mny.y, mnz.y, mxx.y, mxy.y, mxz.y, ro, inv, tmax, &t1))) { r1 = BVH_NO_CHILD; t1 = kInfinity; }
-    if (!(r2 != BVH_NO_CHILD && slab_test6(mnx.z, mny.z, mnz.z, mxx.z, mxy.z, mxz.z, ro, inv, tmax, &t2))) { r2 = BVH_NO_CHILD; t2 = kInfinity; }
-    if (!(r3 != BVH_NO_CHILD && slab_test6(mnx.w, mny.w, mnz.w, mxx.w, mxy.w, mxz.w, ro, inv, tmax, &t3))) { r3 = BVH_NO_CHILD; t3 = kInfinity; }
+    {
+        const bool h0 = slab_test6(mnx.x, mny.x, mnz.x, mxx.x, mxy.x, mxz.x, ro, inv, tmax, &t0) & (r0 != BVH_NO_CHILD);
+        const bool h1 = slab_test6(mnx.y, mny.y, mnz.y, mxx.y, mxy.y, mxz.y, ro, inv, tmax, &t1) & (r1 != BVH_NO_CHILD);
+        const bool h2 = slab_test6(mnx.z, mny.z, mnz.z, mxx.z, mxy.z, mxz.z, ro, inv, tmax, &t2) & (r2 != BVH_NO_CHILD);
+        const bool h3 = slab_test6(mnx.w, mny.w, mnz.w, mxx.w, mxy.w, mxz.w, ro, inv, tmax, &t3) & (r3 != BVH_NO_CHILD);
+        r0 = h0 ? r0 : BVH_NO_CHILD; t0 = h0 ? t0 : kInfinity;
+        r1 = h1 ? r1 : BVH_NO_CHILD; t1 = h1 ? t1 : kInfinity;
+        r2 = h2 ? r2 : BVH_NO_CHILD; t2 = h2 ? t2 : kInfinity;
+        r3 = h3 ? r3 : BVH_NO_CHILD; t3 = h3 ? t3 : kInfinity;
+    }
     BVH4_CSWAP(t0, r0, t1, r1);
     BVH4_CSWAP(t2, r2, t3, r3);
     BVH4_CSWAP(t0, r0, t2, r2);
