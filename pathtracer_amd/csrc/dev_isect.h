@@ -20,45 +20,13 @@ struct SI { /* the fields of SurfaceInteraction the hot path reads (interaction.
     int med_in, med_out;
 };
 
-/* geometry.h:1481-1499 with 1/d hoisted (the reference recomputes it per test; same values) */
-PD bool slab_test(const float *bmin, const float *bmax, const f3 &o, const f3 &inv, float tmax, float *t_entry, float *t_exit = nullptr) {
-    float t0 = 0, t1 = tmax;
-    const float k = 1 + 2 * gammar(3);
-    {
-        float tn = (bmin[0] - o.x) * inv.x, tf = (bmax[0] - o.x) * inv.x;
-        if (tn > tf) { float s = tn; tn = tf; tf = s; }
-        tf *= k;
-        t0 = tn > t0 ? tn : t0;
-        t1 = tf < t1 ? tf : t1;
-        if (t0 > t1) return false;
-    }
-    {
-        float tn = (bmin[1] - o.y) * inv.y, tf = (bmax[1] - o.y) * inv.y;
-        if (tn > tf) { float s = tn; tn = tf; tf = s; }
-        tf *= k;
-        t0 = tn > t0 ? tn : t0;
-        t1 = tf < t1 ? tf : t1;
-        if (t0 > t1) return false;
-    }
-    {
-        float tn = (bmin[2] - o.z) * inv.z, tf = (bmax[2] - o.z) * inv.z;
-        if (tn > tf) { float s = tn; tn = tf; tf = s; }
-        tf *= k;
-        t0 = tn > t0 ? tn : t0;
-        t1 = tf < t1 ? tf : t1;
-        if (t0 > t1) return false;
-    }
-    *t_entry = t0;
-    if (t_exit) *t_exit = t1;
-    return true;
-}
-
-/* The same test on a box given by scalars (a child slot of a 4-wide node), without the early
- * exits: the entry bound only grows and the exit bound only shrinks from axis to axis, so "t0 > t1
- * after some axis" and "t0 > t1 after the last axis" are the same predicate (NaNs from 0 * inf leave
- * both bounds untouched in either form).  Straight-line code: no EXEC-mask juggling per axis, and
- * the four children of a node interleave. */
-PD bool slab_test6(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, const f3 &o, const f3 &inv, float tmax, float *t_entry) {
+/* geometry.h:1481-1499 with 1/d hoisted (the reference recomputes it per test; same values) and
+ * without the early exits: the entry bound only grows and the exit bound only shrinks from axis to
+ * axis, so "t0 > t1 after some axis" and "t0 > t1 after the last axis" are the same predicate (NaNs
+ * from 0 * inf leave both bounds untouched in either form).  Straight-line code: no EXEC-mask
+ * juggling per axis, and the tests of several boxes interleave. */
+PD bool slab_test6(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, const f3 &o, const f3 &inv, float tmax, float *t_entry,
+                   float *t_exit = nullptr) {
     const float k = 1 + 2 * gammar(3);
     float t0 = 0, t1 = tmax;
     {
@@ -80,7 +48,11 @@ PD bool slab_test6(float mnx, float mny, float mnz, float mxx, float mxy, float 
         t1 = hi < t1 ? hi : t1;
     }
     *t_entry = t0;
+    if (t_exit) *t_exit = t1;
     return !(t0 > t1);
+}
+PD bool slab_test(const float *bmin, const float *bmax, const f3 &o, const f3 &inv, float tmax, float *t_entry, float *t_exit = nullptr) {
+    return slab_test6(bmin[0], bmin[1], bmin[2], bmax[0], bmax[1], bmax[2], o, inv, tmax, t_entry, t_exit);
 }
 
 /* One visit of a 4-wide node (dev_scene.h Node128): tests the occupied child slots and leaves the

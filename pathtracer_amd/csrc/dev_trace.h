@@ -254,9 +254,16 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, unsigned *total
                 if (sp == sp_base) mode = TM_TOPLEAF;
                 else node = PT_POP();
             } else {
-                if (nh > 3) PT_PUSH(r3);
-                if (nh > 2) PT_PUSH(r2);
-                if (nh > 1) PT_PUSH(r1);
+                if (sp + 3 <= LDS_STACK) { /* the usual case: three unconditional LDS stores, farthest child deepest */
+                    lds[sp * TRACE_TPB] = nh == 4 ? r3 : (nh == 3 ? r2 : r1);
+                    lds[(sp + 1) * TRACE_TPB] = nh == 4 ? r2 : r1;
+                    lds[(sp + 2) * TRACE_TPB] = r1;
+                    sp += nh - 1;
+                } else {
+                    if (nh > 3) PT_PUSH(r3);
+                    if (nh > 2) PT_PUSH(r2);
+                    if (nh > 1) PT_PUSH(r1);
+                }
                 node = r0;
             }
             if (__popcll(__ballot(mode == TM_GEOM && node >= 0)) < PT_MIN_ACTIVE) break;
