@@ -55,6 +55,23 @@ PD bool slab_test(const float *bmin, const float *bmax, const f3 &o, const f3 &i
     return slab_test6(bmin[0], bmin[1], bmin[2], bmax[0], bmax[1], bmax[2], o, inv, tmax, t_entry, t_exit);
 }
 
+/* The geometry-level form of the test: the same products and the same (1 + 2 gamma(3)) widening,
+ * with the swaps and running bounds as hardware min / max (v_min3 / v_max3).  It answers like
+ * slab_test6 for every ray except one lying exactly in a face plane of the box with a zero direction
+ * component (0 * inf = NaN: the reference's compare-and-select form skips that bound, IEEE min / max
+ * take the other operand) - a case where "enters the box" has no defined answer; these boxes only
+ * gate which leaves of OUR tree are looked at, the top level keeps the reference's exact form. */
+PD bool slab_minmax(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, const f3 &o, const f3 &inv, float tmax, float *t_entry) {
+    const float k = 1 + 2 * gammar(3);
+    const float ax = (mnx - o.x) * inv.x, bx = (mxx - o.x) * inv.x;
+    const float ay = (mny - o.y) * inv.y, by = (mxy - o.y) * inv.y;
+    const float az = (mnz - o.z) * inv.z, bz = (mxz - o.z) * inv.z;
+    const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.f));
+    const float t1 = fminf(fminf(fmaxf(ax, bx) * k, fmaxf(ay, by) * k), fminf(fmaxf(az, bz) * k, tmax));
+    *t_entry = t0;
+    return t0 <= t1;
+}
+
 /* One visit of a 4-wide node (dev_scene.h Node128): tests the occupied child slots and leaves the
  * refs of those the ray enters in r0..r3, nearest first (BVH_NO_CHILD pads the tail).  A sorting
  * network over (entry distance, ref) pairs keeps everything in registers. */
@@ -73,10 +90,10 @@ PD int bvh4_visit(const Node128 *nodes, int node, const f3 &ro, const f3 &inv, f
     float t0 = kInfinity, t1 = kInfinity, t2 = kInfinity, t3 = kInfinity;
     if (tested) *tested += (r0 != BVH_NO_CHILD) + (r1 != BVH_NO_CHILD) + (r2 != BVH_NO_CHILD) + (r3 != BVH_NO_CHILD);
     {
-        const bool h0 = slab_test6(mnx.x, mny.x, mnz.x, mxx.x, mxy.x, mxz.x, ro, inv, tmax, &t0) & (r0 != BVH_NO_CHILD);
-        const bool h1 = slab_test6(mnx.y, mny.y, mnz.y, mxx.y, mxy.y, mxz.y, ro, inv, tmax, &t1) & (r1 != BVH_NO_CHILD);
-        const bool h2 = slab_test6(mnx.z, mny.z, mnz.z, mxx.z, mxy.z, mxz.z, ro, inv, tmax, &t2) & (r2 != BVH_NO_CHILD);
-        const bool h3 = slab_test6(mnx.w, mny.w, mnz.w, mxx.w, mxy.w, mxz.w, ro, inv, tmax, &t3) & (r3 != BVH_NO_CHILD);
+        const bool h0 = slab_minmax(mnx.x, mny.x, mnz.x, mxx.x, mxy.x, mxz.x, ro, inv, tmax, &t0) & (r0 != BVH_NO_CHILD);
+        const bool h1 = slab_minmax(mnx.y, mny.y, mnz.y, mxx.y, mxy.y, mxz.y, ro, inv, tmax, &t1) & (r1 != BVH_NO_CHILD);
+        const bool h2 = slab_minmax(mnx.z, mny.z, mnz.z, mxx.z, mxy.z, mxz.z, ro, inv, tmax, &t2) & (r2 != BVH_NO_CHILD);
+        const bool h3 = slab_minmax(mnx.w, mny.w, mnz.w, mxx.w, mxy.w, mxz.w, ro, inv, tmax, &t3) & (r3 != BVH_NO_CHILD);
         r0 = h0 ? r0 : BVH_NO_CHILD; t0 = h0 ? t0 : kInfinity;
         r1 = h1 ? r1 : BVH_NO_CHILD; t1 = h1 ? t1 : kInfinity;
         r2 = h2 ? r2 : BVH_NO_CHILD; t2 = h2 ? t2 : kInfinity;
