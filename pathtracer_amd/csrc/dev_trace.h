@@ -43,7 +43,7 @@ enum { TM_IDLE = 0, TM_TOP = 1, TM_TOPLEAF = 2, TM_GEOM = 3 };
 
 /* inner loops hand control back (to let finished lanes refill) once this few lanes remain in them */
 #ifndef PT_MIN_ACTIVE
-#define PT_MIN_ACTIVE 20
+#define PT_MIN_ACTIVE 8
 #endif
 /* idle lanes wait until this many can be refilled together */
 #ifndef PT_REFILL
