@@ -19,15 +19,15 @@ enum { MT_MATTE = 1, MT_MIRROR, MT_GLASS, MT_METAL, MT_TRANSLUCENT, MT_PLASTIC, 
  * copy each): fewer spills around them (114 instead of 194 VGPRs), half the compile time, shade 6 % faster. */
 #define LOBE_FN static __device__ __noinline__
 
-struct Lobe {
+struct Lobe { /* 16 words; a field is written only by the lobe kinds that read it */
     int type, impl;
-    f3 S, T;     /* reflectance / transmittance (BxDF::S, BxDF::T) */
-    float A, B;  /* eta pair or Oren-Nayar A,B */
+    f3 S;         /* reflectance (BxDF::S) */
+    f3 T;         /* transmittance (BxDF::T); conductor lobes: etaT spectrum (etaI is always 1) */
+    float A, B;   /* eta pair, or Oren-Nayar A,B; conductor lobes: k.x, k.y */
+    float C;      /* conductor lobes: k.z; BSSRDF adapter: eta of the owning BSSRDF */
     float ax, ay; /* Trowbridge-Reitz alphas */
     int fr_type;
     float fr_etaI, fr_etaT;
-    f3 fr_eta, fr_k; /* conductor: etaT spectrum and k (etaI is always 1) */
-    float bss_eta;   /* BSSRDF adapter: eta of the owning BSSRDF */
 };
 struct BSDF {
     Lobe l[MAX_LOBES];
@@ -74,7 +74,7 @@ PD f3 fr_conductor(float cosThetaI, const f3 &etai, const f3 &etat, const f3 &k)
 }
 PD f3 fresnel_eval(const Lobe &b, float cosI) {
     if (b.fr_type == FR_DIELECTRIC) return f3(fr_dielectric(cosI, b.fr_etaI, b.fr_etaT));
-    if (b.fr_type == FR_CONDUCTOR) return fr_conductor(absr(cosI), f3(1.f), b.fr_eta, b.fr_k);
+    if (b.fr_type == FR_CONDUCTOR) return fr_conductor(absr(cosI), f3(1.f), b.T, f3(b.A, b.B, b.C));
     return f3(1.f);
 }
 
@@ -237,8 +237,8 @@ LOBE_FN f3 lobe_f(const Lobe &b, const f3 &wo, const f3 &wi) {
         return diffuse + specular;
     }
     case LB_BSSRDF_ADAPTER: {
-        f3 f = bssrdf_sw(b.bss_eta, wi);
-        f *= b.bss_eta * b.bss_eta;
+        f3 f = bssrdf_sw(b.C, wi);
+        f *= b.C * b.C;
         return f;
     }
     default: return f3(0.f);
@@ -420,8 +420,7 @@ PD float tex_float(const DScene &sc, const DTex &t, const f2 &uv) {
 
 /* ---- lobe constructors, reflection.h:131-246 ---- */
 PD void lobe_clear(Lobe &b) {
-    b.type = 0; b.impl = LB_INVALID; b.S = f3(0.f); b.T = f3(0.f); b.A = b.B = 0; b.ax = b.ay = 0;
-    b.fr_type = FR_NOOP; b.fr_etaI = b.fr_etaT = 0; b.fr_eta = f3(0.f); b.fr_k = f3(0.f); b.bss_eta = 0;
+    b.type = 0; b.impl = LB_INVALID; b.fr_type = FR_NOOP; /* the rest is set by the constructor of the kind that reads it */
 }
 PD void push_lambert_r(BSDF *b, const f3 &R) { Lobe &l = b->l[b->n++]; lobe_clear(l); l.type = BSDF_REFLECTION | BSDF_DIFFUSE; l.impl = LB_LAMBERT_R; l.S = R; }
 PD void push_lambert_t(BSDF *b, const f3 &T) { Lobe &l = b->l[b->n++]; lobe_clear(l); l.type = BSDF_TRANSMISSION | BSDF_DIFFUSE; l.impl = LB_LAMBERT_T; l.S = T; }
@@ -515,7 +514,8 @@ PD bool compute_scattering(const DScene &sc, const SI &si, BSDF *bsdf, BssrdfPar
         Lobe &l = bsdf->l[bsdf->n++];
         lobe_clear(l);
         l.type = BSDF_REFLECTION | BSDF_GLOSSY; l.impl = LB_MICRO_R; l.S = f3(1.f);
-        l.fr_type = FR_CONDUCTOR; l.fr_eta = tex_spec(sc, tx[0], uv); l.fr_k = tex_spec(sc, tx[1], uv);
+        l.fr_type = FR_CONDUCTOR; l.T = tex_spec(sc, tx[0], uv);
+        { f3 k = tex_spec(sc, tx[1], uv); l.A = k.x; l.B = k.y; l.C = k.z; }
         l.ax = roughness_to_alpha(ur); l.ay = roughness_to_alpha(vr);
     } break;
     case MT_PLASTIC: {

@@ -340,7 +340,7 @@ PD bool bssrdf_step(const DScene &sc, BSDF &bsdf, const BssrdfParams &bp, const 
         lobe_clear(lb);
         lb.type = BSDF_REFLECTION | BSDF_DIFFUSE;
         lb.impl = LB_BSSRDF_ADAPTER;
-        lb.bss_eta = b.eta;
+        lb.C = b.eta;
         pi.wo = pi.n;
     }
     if (is_black(S) || is_zero(pdf)) return false;
