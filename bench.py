@@ -74,8 +74,8 @@ def cpu_baseline(scene, width, height, integrator, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--spp", type=int, default=8, help="samples per pixel per step and per GPU (one batch)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -161,7 +161,7 @@ def main():
 
     # roofline leg (untimed, rank 0's GPU only needs it but every rank runs it to stay in step): passes rendered one
     # at a time, so each launch has the GPU to itself - the condition rocprofv3 --kernel-trace measures under (it
-    # serialises dispatches), whereas in the timed region four passes overlap and every launch shares the GPU.
+    # serialises dispatches), whereas in the timed region six passes overlap and every launch shares the GPU.
     r.profile_reset()
     r.counters_reset()
     for _ in range(2):
@@ -226,7 +226,7 @@ def main():
                          "avg_launch_ms": avg_ms, "rays_per_launch": rays_per_launch, "launches": launches,
                          "measured": "HIP events on the launch stream, passes run one at a time after the timed region (as rocprofv3 serialises them)",
                          "timed_region": {"avg_launch_ms": t_avg_ms, "launches": t_launches, "achieved": t_achieved, "frac": t_achieved / HBM_PEAK_GBS,
-                                          "note": "four passes overlap on four streams: a launch shares the GPU with other passes' kernels"}},
+                                          "note": "six passes overlap on six streams: a launch shares the GPU with other passes' kernels"}},
             "kernels_ms": {k: round(v["total_ms"], 3) for k, v in prof.items() if v["launches"]},
         }
         if not args.no_cpu and world == 1:

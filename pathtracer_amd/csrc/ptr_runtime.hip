@@ -203,7 +203,7 @@ struct ProfSpan {
  * Ray cost is heavy-tailed - a launch over a few hundred late-bounce rays still lasts as long as
  * its longest ray, ~1 ms of dependent loads - so several passes are kept in flight and the tail
  * of one overlaps the bulk of the others. */
-#define N_LANES 4
+#define N_LANES 6 /* passes in flight (each on its own stream, ~5 GB of buffers at 16 M slots): 4 -> 6 gave +3.5 %, 8 no more */
 #define MAX_ITERS 20
 #define LANE_COUNTER_INTS ((7 + 2 * 16) * MAX_ITERS)
 struct Lane {
@@ -225,7 +225,7 @@ struct PtrContext {
     bool has_scene = false, has_camera = false, has_film = false;
     bool scene_has_media = false, scene_all_opaque = false, scene_passthrough = false;
     /* one tracer launch per bounce for {next segments, shadow rays, MIS rays} instead of three: 6 % less GPU
-     * time for a pass that has the GPU to itself, 2 % more when four passes overlap (bench.py): off by default */
+     * time for a pass that has the GPU to itself, 2 % more when several passes overlap (bench.py): off by default */
     bool merge_traces = false;
     bool scene_has_sss = false; /* some material carries a BSSRDF: k_shade<true> / k_finish<true> */
     DCamera cam;
@@ -819,7 +819,7 @@ int ptr_render(PtrContext *ctx, int ns, int integrator) {
     /* first sample index >= begin owned by this shard */
     int stride = ctx->shard_stride;
     int first = begin + ((ctx->shard_offset - begin) % stride + stride) % stride;
-    bool used[N_LANES] = {false, false, false, false};
+    bool used[N_LANES] = {};
     while (first < end) {
         int remaining = (end - first + stride - 1) / stride;
         /* spread the samples of this call over the lanes before filling a lane's batch */
