@@ -4,7 +4,7 @@
 Workload at N=1 (BASELINE.json configs[1]): 871,200-triangle torus-knot mesh ("dragon-class"
 stand-in, the author's assets are not available), rough-glass microfacet material, light-map
 sky, 1920x1080, Li_VolPath (the reference's default integrator, main.cpp:447).  One *step* is one
-batch of --spp (8) samples of every pixel - 1/32 of the 256 spp of configs[1] - through the wavefront pipeline (raygen -> {trace, shade, nee} per
+batch of --spp (16) samples of every pixel - 1/16 of the 256 spp of configs[1] - through the wavefront pipeline (raygen -> {trace, shade, nee} per
 bounce -> film); scene, BVH and film are resident in HBM before the timed region starts.
 
 value = (closest-hit + any-hit scene queries of all ranks) / wall time, in Mrays/s.
@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--spp", type=int, default=8, help="samples per pixel per step and per GPU (one batch)")
+    ap.add_argument("--spp", type=int, default=16, help="samples per pixel per step and per GPU (one batch)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--segments", type=int, default=660, help="knot tessellation: 2*s*s triangles (660 -> 871,200)")

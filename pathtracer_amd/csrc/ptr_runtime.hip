@@ -756,8 +756,9 @@ int ptr_film_init(PtrContext *ctx, int width, int height, uint64_t seed) {
     if (!ctx->has_film || npix != ctx->npix) {
         free_film(ctx);
         /* samples per pass: launches last as long as their longest ray (~2 ms on config[1]) while
-         * the marginal cost is ~0.25 ns per ray, so a pass should carry ~16 M path slots */
-        long long target = 1ll << 24;
+         * the marginal cost is ~0.25 ns per ray, so a pass should carry tens of millions of path slots
+         * (config[1]: 16 M -> 1110, 32 M -> 1185, 64 M -> 1207 Mrays/s; ~300 B of HBM per slot and lane) */
+        long long target = 1ll << 25;
         if (const char *e = getenv("PTR_PASS_SLOTS")) { /* tuning experiments */
             long long v = atoll(e);
             if (v > 0) target = v;
