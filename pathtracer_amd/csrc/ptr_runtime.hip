@@ -83,51 +83,73 @@ __global__ void __launch_bounds__(TPB) k_raygen_only(DCamera cam, PassParams prm
     if (w_out) w_out[p] = w;
 }
 
-/* ---- bin the live paths by what they hit, so that a wavefront of k_shade runs one material's code
- * (miss / emitter / no material / the ten material types): two streaming passes, count then
- * scatter, wave-aggregated atomics per class.  The arithmetic of a path does not depend on where
- * in the queue it sits. */
-#define N_CLASSES 16
-PD int shade_class(const DScene &sc, int hp) {
-    if (hp < 0) return 0;
-    const DPrim &pr = sc.prims[hp];
-    if (pr.flags & PF_EMISSIVE) return 1;
-    if (pr.material < 0) return 2;
-    int t = sc.mats[pr.material].type;
-    return 3 + (t < 0 ? 0 : (t > 12 ? 12 : t));
-}
-__global__ void __launch_bounds__(TPB) k_bin_count(DScene sc, Pipe pp, const int *n_ptr, int n_host, const int *queue, int *cls_count) {
-    GRID_STRIDE_BEGIN(n_ptr, n_host)
-    int cls = -1;
-    if (i < n) cls = shade_class(sc, pp.hprim[queue ? queue[i] : i]);
-    for (int c = 0; c < N_CLASSES; c++) {
-        unsigned long long m = __ballot(cls == c);
-        if (m && __lane_id() == __ffsll((long long)m) - 1) atomicAdd(&cls_count[c], __popcll(m));
-    }
-    GRID_STRIDE_END
-}
-__global__ void __launch_bounds__(TPB) k_bin_scatter(DScene sc, Pipe pp, const int *n_ptr, int n_host, const int *queue, const int *cls_count,
-                                                     int *cls_cursor, int *q_out) {
-    GRID_STRIDE_BEGIN(n_ptr, n_host)
-    int cls = -1, slot = 0;
-    if (i < n) {
-        slot = queue ? queue[i] : i;
-        cls = shade_class(sc, pp.hprim[slot]);
-    }
-    int start = 0; /* first index of my class in the output */
-    for (int c = 0; c < N_CLASSES; c++) {
-        int cnt = cls_count[c];
-        unsigned long long m = __ballot(cls == c);
-        if (m) {
-            int leader = __ffsll((long long)m) - 1;
-            int base = 0;
-            if (__lane_id() == leader) base = atomicAdd(&cls_cursor[c], __popcll(m));
-            base = __shfl(base, leader, 64);
-            if (cls == c) q_out[start + base + __popcll(m & ((1ull << __lane_id()) - 1ull))] = slot;
+/* Paths whose ray left the scene outside any medium end here: sky radiance if the integrator adds
+ * it at this vertex (main.cpp:83-86, 124-127 / 179-181, 402-404), counters.  All other live paths are
+ * compacted, in order, into the queue the shade kernel reads, so that its wavefronts hold only
+ * vertices that run the surface / medium code: from the second bounce on about half of all rays
+ * escape to the sky, and a shade wavefront costs the same whether 30 or 64 of its lanes hit. */
+#define MISS_CHUNK 8 /* groups of 64 queue entries a wavefront handles per reservation in the output queue */
+__global__ void __launch_bounds__(TPB) k_miss(DScene sc, Pipe pp, PassParams prm, const int *n_ptr, int n_host, const int *queue, int *q_hit,
+                                              int *hit_count, unsigned long long *ctrs) {
+    unsigned total = 0, miss = 0;
+    const int n = n_ptr ? *n_ptr : n_host;
+    const int lane = __lane_id();
+    const int wave = (blockIdx.x * TPB + threadIdx.x) >> 6, n_waves = (gridDim.x * TPB) >> 6;
+    const int cap = pp.cap;
+    /* a wavefront takes MISS_CHUNK x 64 consecutive entries and reserves its share of the output
+     * queue with ONE atomic: this kernel is fast enough for a per-group atomic on one address
+     * (half a million of them per bounce) to be what it waits for */
+    for (long long base = (long long)wave * 64 * MISS_CHUNK; base < n; base += (long long)n_waves * 64 * MISS_CHUNK) {
+        int slots[MISS_CHUNK];
+        unsigned long long masks[MISS_CHUNK];
+        int kept = 0;
+#pragma unroll
+        for (int c = 0; c < MISS_CHUNK; c++) {
+            const long long i = base + c * 64 + lane;
+            bool keep = false;
+            int slot = 0;
+            if (i < n) {
+                slot = queue ? queue[i] : (int)i;
+                const int hp = pp.hprim[slot];
+                const int med = (int)pp.paths[(size_t)WORD_OF(PathRec, medium) * cap + slot];
+                keep = hp >= 0 || med >= 0;
+                if (!keep) {
+                    PathRec ps;
+                    soa_load<0, WORD_OF(PathRec, dim)>(pp.paths, cap, slot, &ps); /* L, beta, bounces, flags */
+                    const f3 rd(pp.rd[slot], pp.rd[cap + slot], pp.rd[2 * cap + slot]);
+                    f3 L = ld3(ps.L);
+                    const f3 beta = ld3(ps.beta);
+                    total++;
+                    if (prm.integrator == PTR_LI_DIRECT) {
+                        for (int k = 0; k < sc.n_lights; k++) L += light_le(sc, sc.lights[k], rd);
+                    } else if (prm.integrator == PTR_LI_PATH) {
+                        L = sum_lights_le(sc, rd, beta, L);
+                        miss++;
+                        if (ps.bounces == 10 - 1) L = f3(0.f); /* sic, main.cpp:408 */
+                    } else {
+                        miss++;
+                        const bool beta_gone = prm.integrator == PTR_LI_VOLPATH && is_black(beta); /* main.cpp:164 */
+                        if (!beta_gone && (ps.bounces == 0 || (ps.flags & PFL_SPECULAR))) L = sum_lights_le(sc, rd, beta, L);
+                    }
+                    st3(ps.L, L);
+                    soa_store<0, 3>(pp.paths, cap, slot, &ps);
+                }
+            }
+            slots[c] = slot;
+            masks[c] = __ballot(keep);
+            kept += __popcll(masks[c]);
         }
-        start += cnt;
+        int out = 0;
+        if (lane == 0 && kept) out = atomicAdd(hit_count, kept);
+        out = __shfl(out, 0, 64);
+#pragma unroll
+        for (int c = 0; c < MISS_CHUNK; c++) {
+            if ((masks[c] >> lane) & 1ull) q_hit[out + __popcll(masks[c] & ((1ull << lane) - 1ull))] = slots[c];
+            out += __popcll(masks[c]);
+        }
     }
-    GRID_STRIDE_END
+    ctr_flush(ctrs, C_TOTAL, total);
+    ctr_flush(ctrs, C_MISS, miss);
 }
 
 /* sum of a direct-light record whose two rays went through the persistent tracer */
@@ -189,9 +211,9 @@ static int set_err(int code, const std::string &msg) {
         if (e_ != hipSuccess) return set_err(PTR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-enum { K_RAYGEN = 0, K_TRACE, K_SHADE, K_SHADOW, K_MIS, K_RESOLVE, K_FILM, K_FINISH, K_API_TRACE = K_TRACE };
+enum { K_RAYGEN = 0, K_TRACE, K_SHADE, K_SHADOW, K_MIS, K_RESOLVE, K_FILM, K_FINISH, K_MISS, K_API_TRACE = K_TRACE };
 static const char *kKernelNames[PTR_PROF_KERNELS] = {"raygen", "trace_closest", "shade", "nee_shadow", "nee_mis", "nee_resolve", "film",
-                                                     "finish"};
+                                                     "finish", "miss"};
 
 struct ProfSpan {
     hipEvent_t a, b;
@@ -205,13 +227,13 @@ struct ProfSpan {
  * of one overlaps the bulk of the others. */
 #define N_LANES 6 /* passes in flight (each on its own stream, ~5 GB of buffers at 16 M slots): 4 -> 6 gave +3.5 %, 8 no more */
 #define MAX_ITERS 20
-#define LANE_COUNTER_INTS ((7 + 2 * 16) * MAX_ITERS)
+#define LANE_COUNTER_INTS (8 * MAX_ITERS)
 struct Lane {
     hipStream_t stream = nullptr;
     Pipe pipe;
     int *queues[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; /* ping, pong, nee, shadow, mis, binned */
     int *counts = nullptr;      /* device: [MAX_ITERS][4] = next, nee, shadow, mis; [MAX_ITERS][3] ray-fetch cursors;
-                                   [MAX_ITERS][2][N_CLASSES] class counts and scatter cursors */
+                                   [MAX_ITERS] live paths that did not end in the miss pre-pass */
     int *counts_host = nullptr; /* pinned: the [MAX_ITERS][4] counts of the last finished pass */
     hipEvent_t film_done = nullptr, joined = nullptr;
     int staged_used = 0, slots_used = 0; /* of the pass last queued on this lane */
@@ -242,8 +264,6 @@ struct PtrContext {
     int next_lane = 0, last_film_lane = -1;
     int staged_bounces = 6; /* wavefront bounces before k_finish; adapted from the live counts of finished passes */
     bool staged_fixed = false;
-    bool bin_by_material = false; /* measured on config[1]: the two extra passes and the loss of slot-order locality cost more
-                                     than the divergence they remove (725 vs 875 Mrays/s); kept for experiments (PTR_BIN=1) */
     int spread = 1; /* a ptr_render call deals its samples to this many passes (lanes) */
     int *api_fetch = nullptr; /* ray-fetch cursors of the stand-alone trace entry points (rotating) */
     int api_fetch_next = 0;
@@ -416,18 +436,14 @@ static void enqueue_shade(PtrContext *ctx, Lane &l, const PassParams &prm, const
     hipStream_t s = l.stream;
     int *cnt = l.counts + 4 * cslot;
     const unsigned stride_blocks = clampu(nblocks(n_upper), 32, 2048);
-    const int *q_shade = q_cur;
-    if (ctx->bin_by_material) {
-        int *cls = l.counts + 7 * MAX_ITERS + 2 * N_CLASSES * cslot;
-        ProfScope ps(ctx, s, K_SHADE, 0);
-        hipLaunchKernelGGL(k_bin_count, dim3(stride_blocks), dim3(TPB), 0, s, ctx->sc, l.pipe, n_ptr, n_host, q_cur, cls);
-        hipLaunchKernelGGL(k_bin_scatter, dim3(stride_blocks), dim3(TPB), 0, s, ctx->sc, l.pipe, n_ptr, n_host, q_cur, (const int *)cls,
-                           cls + N_CLASSES, l.queues[5]);
-        q_shade = l.queues[5];
+    int *hit_count = l.counts + 7 * MAX_ITERS + cslot;
+    {
+        ProfScope ps(ctx, s, K_MISS, 0);
+        hipLaunchKernelGGL(k_miss, dim3(stride_blocks), dim3(TPB), 0, s, ctx->sc, l.pipe, prm, n_ptr, n_host, q_cur, l.queues[5], hit_count, ctx->ctrs);
     }
-    ProfScope ps(ctx, s, K_SHADE, (uint64_t)(n_ptr ? 0 : n_host));
+    ProfScope ps(ctx, s, K_SHADE, 0);
     const int walk_i = prm.integrator == PTR_LI_VOLPATH && !ctx->scene_all_opaque ? 1 : 0;
-    const ShadeArgs a = {ctx->sc, l.pipe, prm, n_ptr, n_host, q_shade, q_next, l.queues[2], l.queues[3], l.queues[4], cnt, walk_i, ctx->ctrs};
+    const ShadeArgs a = {ctx->sc, l.pipe, prm, hit_count, 0, l.queues[5], q_next, l.queues[2], l.queues[3], l.queues[4], cnt, walk_i, ctx->ctrs};
     if (ctx->scene_has_sss) rt_launch_shade_sss(stride_blocks, s, a);
     else rt_launch_shade(stride_blocks, s, a);
 }
@@ -606,7 +622,6 @@ int ptr_create(int device, PtrContext **out) {
         if (v > 0) { ctx->staged_bounces = v; ctx->staged_fixed = true; }
     }
     if (const char *e = getenv("PTR_MERGE")) ctx->merge_traces = atoi(e) != 0; /* tuning experiments */
-    if (const char *e = getenv("PTR_BIN")) ctx->bin_by_material = atoi(e) != 0; /* tuning experiments */
     if (const char *e = getenv("PTR_SPREAD")) { /* tuning experiments */
         int v = atoi(e);
         if (v > 0) ctx->spread = v;
