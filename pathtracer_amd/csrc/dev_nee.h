@@ -37,7 +37,16 @@ PD Rng make_rng(uint64_t seed, uint32_t pixel, uint32_t sample) {
 PD f2 rand2(Rng &r) { float y = r.next(); float x = r.next(); return f2(x, y); }
 PD f3 rand3(Rng &r) { float z = r.next(); float y = r.next(); float x = r.next(); return f3(x, y, z); }
 
-/* ---- records in HBM ---- */
+/* ---- records in HBM ----
+ * A record type of W words is stored as word planes, TILED: slots are grouped in tiles of
+ * 2^PLANE_TILE_SHIFT, and a tile holds its W planes back to back (word w of slot s at
+ * ((s >> T) * W + w) << T | (s & (2^T - 1))).  Consecutive lanes still read consecutive words, but all
+ * the fields of the 64 records a wavefront works on lie within W * 4 KiB instead of W different
+ * regions cap * 4 bytes apart - one or two pages for the TLB instead of sixty. */
+#define PLANE_TILE_SHIFT 10
+PD size_t plane_at(int W, int slot, int w) {
+    return ((((size_t)(slot >> PLANE_TILE_SHIFT)) * W + w) << PLANE_TILE_SHIFT) | (size_t)(slot & ((1 << PLANE_TILE_SHIFT) - 1));
+}
 enum { PFL_SPECULAR = 1 };
 struct __attribute__((aligned(16))) PathRec {
     float L[3], beta[3];
@@ -80,10 +89,9 @@ struct NeeToStruct {
 };
 struct NeeToPlanes {
     float *base;
-    size_t cap;
     int slot;
-    PD void put(int w, float v) const { base[w * cap + slot] = v; }
-    PD void puti(int w, int v) const { base[w * cap + slot] = __int_as_float(v); }
+    PD void put(int w, float v) const { base[plane_at((int)(sizeof(NeeRec) / 4), slot, w)] = v; }
+    PD void puti(int w, int v) const { base[plane_at((int)(sizeof(NeeRec) / 4), slot, w)] = __int_as_float(v); }
     PD void put3(int w, const f3 &v) const { put(w, v.x); put(w + 1, v.y); put(w + 2, v.z); }
 };
 

@@ -13,6 +13,7 @@
  */
 #pragma once
 #include "dev_isect.h"
+#include "dev_nee.h"
 
 struct TraceIO {
     const int *queue; /* ray slots, or null for identity */
@@ -29,6 +30,10 @@ struct TraceIO {
     char *prim, *face, *t, *b0, *b1;
     long long prim_es, face_es, t_es, b0_es, b1_es;
     int *counter; /* ray-fetch cursor, zero at launch */
+    /* rays and results inside tiled word planes (dev_nee.h plane_at; the direct-light records):
+     * tile_words = words per record (0: the byte strides above apply), o / prim = the plane base,
+     * w_o, w_d, w_prim, w_t = first word of origin, direction, prim result, t result (-1: none) */
+    int tile_words, w_o, w_d, w_prim, w_t;
 };
 
 enum { TM_IDLE = 0, TM_TOP = 1, TM_TOPLEAF = 2, TM_GEOM = 3 };
@@ -52,6 +57,15 @@ enum { TM_IDLE = 0, TM_TOP = 1, TM_TOPLEAF = 2, TM_GEOM = 3 };
 
 PD void trace_io_fetch(const TraceIO &io, int idx, int *slot, f3 *ro, f3 *rd, float *tmax) {
     const int s = io.queue ? io.queue[idx] : idx;
+    if (io.tile_words) {
+        const float *b = reinterpret_cast<const float *>(io.o);
+        const size_t step = (size_t)1 << PLANE_TILE_SHIFT, io0 = plane_at(io.tile_words, s, io.w_o), id0 = plane_at(io.tile_words, s, io.w_d);
+        *ro = f3(b[io0], b[io0 + step], b[io0 + 2 * step]);
+        *rd = f3(b[id0], b[id0 + step], b[id0 + 2 * step]);
+        *tmax = io.tmax_const;
+        *slot = s;
+        return;
+    }
     const char *po = io.o + (long long)s * io.o_es;
     const char *pd = io.d + (long long)s * io.d_es;
     *ro = f3(*(const float *)po, *(const float *)(po + io.o_cs), *(const float *)(po + 2 * io.o_cs));
@@ -61,6 +75,12 @@ PD void trace_io_fetch(const TraceIO &io, int idx, int *slot, f3 *ro, f3 *rd, fl
 }
 template <bool COUNT>
 PD void trace_io_store(const TraceIO &io, bool any, int slot, bool hit, int hp, int hf, float tmax, float hb0, float hb1, unsigned rn, unsigned ri) {
+    if (io.tile_words) {
+        int *b = reinterpret_cast<int *>(io.prim);
+        b[plane_at(io.tile_words, slot, io.w_prim)] = any ? (hit ? 1 : 0) : (hit ? hp : -1);
+        if (!any && io.w_t >= 0) b[plane_at(io.tile_words, slot, io.w_t)] = __float_as_int(tmax);
+        return;
+    }
     if (any) {
         if (io.prim) *(int *)(io.prim + (long long)slot * io.prim_es) = hit ? 1 : 0;
         return;

@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(TPB) k_miss(DScene sc, Pipe pp, PassParams prm
             if (i < n) {
                 slot = queue ? queue[i] : (int)i;
                 const int hp = pp.hprim[slot];
-                const int med = (int)pp.paths[(size_t)WORD_OF(PathRec, medium) * cap + slot];
+                const int med = (int)pp.paths[plane_at(PATH_WORDS, slot, WORD_OF(PathRec, medium))];
                 keep = hp >= 0 || med >= 0;
                 if (!keep) {
                     PathRec ps;
@@ -405,29 +405,24 @@ static TraceIO path_io(const Lane &l, const int *queue, const int *n_ptr, int n_
     return io;
 }
 static TraceIO shadow_io(const Lane &l, const int *queue, const int *n_ptr, int *cursor) { /* any hit within (0, 1 - ShadowEpsilon) */
-    const char *nee = (const char *)l.pipe.nee;
-    const long long plane = 4ll * l.pipe.cap; /* bytes between the planes of consecutive words */
     TraceIO io;
     memset(&io, 0, sizeof(io));
     io.queue = queue; io.n_ptr = n_ptr;
-    io.o = nee + WORD_OF(NeeRec, oA) * plane; io.o_es = 4; io.o_cs = plane;
-    io.d = nee + WORD_OF(NeeRec, dA) * plane; io.d_es = 4; io.d_cs = plane;
+    io.tile_words = NEE_WORDS;
+    io.o = (const char *)l.pipe.nee; io.w_o = WORD_OF(NeeRec, oA); io.w_d = WORD_OF(NeeRec, dA);
     io.tmax_const = 1 - 0.0001f;
-    io.prim = (char *)nee + WORD_OF(NeeRec, occA) * plane; io.prim_es = 4;
+    io.prim = (char *)l.pipe.nee; io.w_prim = WORD_OF(NeeRec, occA); io.w_t = -1;
     io.counter = cursor;
     return io;
 }
 static TraceIO mis_io(const Lane &l, const int *queue, const int *n_ptr, int *cursor) { /* closest hit */
-    const char *nee = (const char *)l.pipe.nee;
-    const long long plane = 4ll * l.pipe.cap;
     TraceIO io;
     memset(&io, 0, sizeof(io));
     io.queue = queue; io.n_ptr = n_ptr;
-    io.o = nee + WORD_OF(NeeRec, oB) * plane; io.o_es = 4; io.o_cs = plane;
-    io.d = nee + WORD_OF(NeeRec, dB) * plane; io.d_es = 4; io.d_cs = plane;
+    io.tile_words = NEE_WORDS;
+    io.o = (const char *)l.pipe.nee; io.w_o = WORD_OF(NeeRec, oB); io.w_d = WORD_OF(NeeRec, dB);
     io.tmax_const = FLT_MAX;
-    io.prim = (char *)nee + WORD_OF(NeeRec, hitB) * plane; io.prim_es = 4;
-    io.t = (char *)nee + WORD_OF(NeeRec, tB) * plane; io.t_es = 4;
+    io.prim = (char *)l.pipe.nee; io.w_prim = WORD_OF(NeeRec, hitB); io.w_t = WORD_OF(NeeRec, tB);
     io.counter = cursor;
     return io;
 }
@@ -788,13 +783,14 @@ int ptr_film_init(PtrContext *ctx, int width, int height, uint64_t seed) {
         HIPCHK(hipMalloc((void **)&ctx->acc, sizeof(double) * npix));
         HIPCHK(hipMalloc((void **)&ctx->samples, sizeof(long long) * npix));
         for (Lane &l : ctx->lanes) {
+            const size_t cap_tiles = ((cap + ((size_t)1 << PLANE_TILE_SHIFT) - 1) >> PLANE_TILE_SHIFT) << PLANE_TILE_SHIFT; /* whole tiles */
             HIPCHK(hipMalloc((void **)&l.pipe.ro, 3 * sizeof(float) * cap));
             HIPCHK(hipMalloc((void **)&l.pipe.rd, 3 * sizeof(float) * cap));
             HIPCHK(hipMalloc((void **)&l.pipe.hprim, sizeof(int) * cap));
             HIPCHK(hipMalloc((void **)&l.pipe.hface, sizeof(int) * cap));
             HIPCHK(hipMalloc((void **)&l.pipe.ht, sizeof(float) * cap));
-            HIPCHK(hipMalloc((void **)&l.pipe.paths, sizeof(PathRec) * cap)); /* PATH_WORDS planes */
-            HIPCHK(hipMalloc((void **)&l.pipe.nee, sizeof(NeeRec) * cap));     /* NEE_WORDS planes */
+            HIPCHK(hipMalloc((void **)&l.pipe.paths, sizeof(PathRec) * cap_tiles)); /* PATH_WORDS tiled planes */
+            HIPCHK(hipMalloc((void **)&l.pipe.nee, sizeof(NeeRec) * cap_tiles));     /* NEE_WORDS tiled planes */
             for (int q = 0; q < 6; q++) HIPCHK(hipMalloc((void **)&l.queues[q], sizeof(int) * cap));
             HIPCHK(hipMalloc((void **)&l.counts, LANE_COUNTER_INTS * sizeof(int)));
             HIPCHK(hipHostMalloc((void **)&l.counts_host, 4 * MAX_ITERS * sizeof(int), hipHostMallocDefault));

@@ -19,8 +19,8 @@ struct Pipe {
     float *ro, *rd;      /* 3 planes of cap floats each */
     int *hprim, *hface;
     float *ht;
-    uint32_t *paths; /* PathRec as PATH_WORDS planes of cap words: word w of slot s at paths[w * cap + s] */
-    uint32_t *nee;   /* NeeRec as NEE_WORDS planes */
+    uint32_t *paths; /* PathRec as PATH_WORDS tiled planes (dev_nee.h: plane_at) */
+    uint32_t *nee;   /* NeeRec as NEE_WORDS tiled planes */
     int cap;
 };
 struct PassParams {
@@ -40,12 +40,12 @@ struct PassParams {
 template <int W0, int W1, typename T> PD void soa_load(const uint32_t *base, int cap, int slot, T *rec) {
     uint32_t *o = reinterpret_cast<uint32_t *>(rec);
 #pragma unroll
-    for (int w = W0; w < W1; w++) o[w] = base[(size_t)w * cap + slot];
+    for (int w = W0; w < W1; w++) o[w] = base[plane_at((int)(sizeof(T) / 4), slot, w)];
 }
 template <int W0, int W1, typename T> PD void soa_store(uint32_t *base, int cap, int slot, const T *rec) {
     const uint32_t *o = reinterpret_cast<const uint32_t *>(rec);
 #pragma unroll
-    for (int w = W0; w < W1; w++) base[(size_t)w * cap + slot] = o[w];
+    for (int w = W0; w < W1; w++) base[plane_at((int)(sizeof(T) / 4), slot, w)] = o[w];
 }
 #define NEE_A_BEGIN WORD_OF(NeeRec, fA)
 #define NEE_A_END WORD_OF(NeeRec, fB)

@@ -29,7 +29,7 @@ k_shade(DScene sc, Pipe pp, PassParams prm, const int *n_ptr, int n_host, const 
         int cap = pp.cap;
         PathRec ps;
         soa_load<0, PATH_WORDS>(pp.paths, cap, slot, &ps);
-        const NeeToPlanes rec = {reinterpret_cast<float *>(pp.nee), (size_t)cap, slot};
+        const NeeToPlanes rec = {reinterpret_cast<float *>(pp.nee), slot};
         f3 ro(pp.ro[slot], pp.ro[cap + slot], pp.ro[2 * cap + slot]);
         f3 rd(pp.rd[slot], pp.rd[cap + slot], pp.rd[2 * cap + slot]);
         int pixel = slot % prm.npix;
