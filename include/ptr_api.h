@@ -258,6 +258,23 @@ int ptr_sync(PtrContext *ctx);
  * graphy.cpp:71-93): copies Pixel::we (3 floats/pixel), Pixel::accWeight, Pixel::samples
  * to host arrays (any may be NULL).  Synchronises. */
 int ptr_film_read(PtrContext *ctx, float *we_rgb, double *acc_weight, int64_t *samples);
+/* Replaces the loop of ImageWrite over GetPixelRGB (camera.cpp:36-51, 53-68): resolves the film on
+ * the device - e = we / accWeight, tone map PTR_TONEMAP_* with `exposure` (ReinhardMap /
+ * ExponentialMap / NaughtyDogMap, camera.cpp:6-33), sRGB GammaCorrect (geometry.h:73-76),
+ * (int)(255.999 * e) narrowed to a byte - and copies width*height*3 bytes to `rgb` in pixel order
+ * (row 0 = bottom of the frame, like the Pixel array).  Pixels with zero accWeight give 0 (the
+ * reference asserts).  Synchronises.  SURVEY section 8(f) row 2. */
+#define PTR_TONEMAP_REINHARD 0
+#define PTR_TONEMAP_EXPONENTIAL 1
+#define PTR_TONEMAP_NAUGHTYDOG 2
+int ptr_film_rgb8(PtrContext *ctx, float exposure, int algorithm, unsigned char *rgb);
+/* Inverse of ptr_film_read: overwrites the accumulators of every pixel (host arrays of the same
+ * shapes).  The reference keeps Pixel[] in managed memory, so host code that restores a saved film
+ * writes image->pixels directly (camera.h:23-36); this is that write.  A film restored this way and
+ * rendered further continues the sample sequence: the next ptr_render call starts at sample index
+ * `next_sample` (-1: take samples[0], right for a film that holds every sample so far; ranks of a
+ * sharded render that restart from an empty film pass the saved index).  Synchronises. */
+int ptr_film_write(PtrContext *ctx, const float *we_rgb, const double *acc_weight, const int64_t *samples, int64_t next_sample);
 /* Device addresses of the accumulators, for an RCCL reduce across ranks (no counterpart). */
 int ptr_film_device_ptrs(PtrContext *ctx, void **we_rgb, void **acc_weight, void **samples);
 /* Replaces ImageStats (camera.cpp:86-125). Synchronises. */

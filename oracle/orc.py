@@ -35,6 +35,7 @@ def lib():
         L.orc_glibc_rand.argtypes = [C.c_int]
         L.orc_rng_draw.restype = C.c_float
         L.orc_rng_draw.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.orc_film_rgb8.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p]
         _lib = L
     return _lib
 
@@ -119,3 +120,14 @@ def image_of(we, acc):
         img = we / acc[:, None].astype(np.float32)
     img[~np.isfinite(img)] = 0
     return img
+
+
+def film_rgb8(we, acc, exposure=2.0, algorithm=1):
+    """GetPixelRGB + ImageWrite's byte narrowing over a film (orc_film.cpp); uint8 [..., 3]."""
+    we = np.ascontiguousarray(we, dtype=np.float32)
+    acc = np.ascontiguousarray(acc, dtype=np.float64)
+    out = np.empty(we.shape, np.uint8)
+    rc = lib().orc_film_rgb8(acc.size, we.ctypes.data, acc.ctypes.data, C.c_float(exposure), int(algorithm), out.ctypes.data)
+    if rc:
+        raise ValueError("unknown tone mapping algorithm")
+    return out

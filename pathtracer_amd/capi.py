@@ -14,6 +14,7 @@ HOST_LIB = os.path.join(LIB_DIR, "libpt_host.so")
 
 PTR_OK, PTR_ERR_INVALID, PTR_ERR_HIP, PTR_ERR_STATE, PTR_ERR_LIMIT = 0, 1, 2, 3, 4
 LI_DIRECT, LI_PATH, LI_PATHSAMPLED, LI_VOLPATH = 0, 1, 2, 3
+TONEMAP_REINHARD, TONEMAP_EXPONENTIAL, TONEMAP_NAUGHTYDOG = 0, 1, 2
 SHAPE_SPHERE, SHAPE_RECTANGLE, SHAPE_DISK, SHAPE_BOX, SHAPE_MESH, SHAPE_PARTICLECLOUD = 0, 1, 2, 3, 4, 5
 SHAPE_SPHERE_PROCEDURAL, SHAPE_BOX_PROCEDURAL, SHAPE_COMPONENT_PROCEDURAL = 6, 7, 8
 MAT_NONE, MAT_MATTE, MAT_MIRROR, MAT_GLASS, MAT_METAL, MAT_TRANSLUCENT, MAT_PLASTIC, MAT_UBER = range(8)
@@ -106,6 +107,8 @@ HIP_SIGNATURES = {
     "ptr_render": (C.c_int, [CTX, C.c_int, C.c_int]),
     "ptr_sync": (C.c_int, [CTX]),
     "ptr_film_read": (C.c_int, [CTX, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ptr_film_rgb8": (C.c_int, [CTX, C.c_float, C.c_int, C.c_void_p]),
+    "ptr_film_write": (C.c_int, [CTX, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "ptr_film_device_ptrs": (C.c_int, [CTX, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "ptr_counters_read": (C.c_int, [CTX, C.POINTER(PtrCounters)]),
     "ptr_counters_reset": (C.c_int, [CTX]),
@@ -124,6 +127,9 @@ HOST_SIGNATURES = {
     "pth_scene_rand_calls": (C.c_int, [C.c_void_p]),
     "pth_scene_free": (None, [C.c_void_p]),
     "pth_transform": (None, [C.c_char_p, f32, f32, f32, f32, C.POINTER(PtrTransform)]),
+    "pth_png_encode": (C.c_long, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_long]),
+    "pth_image_write": (C.c_int, [CTX, C.c_int, C.c_int, C.c_char_p, C.c_float, C.c_int]),
+    "pth_ppm_read": (C.c_int, [C.c_char_p, C.c_void_p, C.c_long, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pth_camera_config": (None, [fptr, fptr, fptr, f32, f32, f32, C.POINTER(PtrCamera)]),
 }
 

@@ -50,6 +50,10 @@ enum { TM_IDLE = 0, TM_TOP = 1, TM_TOPLEAF = 2, TM_GEOM = 3 };
 #ifndef PT_MIN_ACTIVE
 #define PT_MIN_ACTIVE 8
 #endif
+/* rays a wavefront reserves per atomic on the queue cursor */
+#ifndef PT_POOL
+#define PT_POOL 64
+#endif
 /* idle lanes wait until this many can be refilled together */
 #ifndef PT_REFILL
 #define PT_REFILL 24
@@ -179,12 +183,12 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, unsigned *total
         if (idle && (__popcll(idle) >= PT_REFILL || __ballot(mode == TM_GEOM) == 0)) {
             if (pool_pos >= pool_end && !exhausted) {
                 int base = 0;
-                if (lane == 0) base = atomicAdd(src.counter, 64);
+                if (lane == 0) base = atomicAdd(src.counter, PT_POOL);
                 base = __shfl(base, 0, 64);
                 if (base >= n_rays) exhausted = true;
                 else {
                     pool_pos = base;
-                    pool_end = base + 64 < n_rays ? base + 64 : n_rays;
+                    pool_end = base + PT_POOL < n_rays ? base + PT_POOL : n_rays;
                 }
             }
             const int avail = pool_end - pool_pos;

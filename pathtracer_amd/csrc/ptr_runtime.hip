@@ -70,6 +70,40 @@ __global__ void __launch_bounds__(TPB) k_raygen(DScene sc, DCamera cam, Pipe pp,
     soa_store<0, PATH_WORDS>(pp.paths, pp.cap, slot, &ps);
 }
 
+/* GetPixelRGB (camera.cpp:36-51) with the three tone maps (camera.cpp:6-33) and GammaCorrect
+ * (geometry.h:73-76): 28 B in, 3 B out per pixel */
+PD float gamma_correct(float v) {
+    if (v <= 0.0031308f) return 12.92f * v;
+    return 1.055f * powf(v, (float)(1.f / 2.4f)) - 0.055f;
+}
+__global__ void __launch_bounds__(TPB) k_tonemap(const float *we, const double *acc, int npix, float exposure, int algo, unsigned char *out) {
+    int p = blockIdx.x * TPB + threadIdx.x;
+    if (p >= npix) return;
+    f3 e(we[3 * p], we[3 * p + 1], we[3 * p + 2]);
+    const double a = acc[p];
+    float invNs = (float)(1.0f / a);
+    e *= invNs;
+    if (algo == PTR_TONEMAP_REINHARD) {
+        e = f3(e.x * (1.0f / (e.x + 1.f)), e.y * (1.0f / (e.y + 1.f)), e.z * (1.0f / (e.z + 1.f))); /* vec / vec: component-wise product with the reciprocals */
+    } else if (algo == PTR_TONEMAP_EXPONENTIAL) {
+        f3 v = -e * exposure;
+        e = f3(1.f) - f3(expf(v.x), expf(v.y), expf(v.z));
+    } else {
+        const float A = 0.15f, B = 0.50f, C = 0.10f, D = 0.20f, E = 0.02f, F = 0.30f, W = 11.2f;
+        e *= exposure;
+        f3 num = e * (A * e + f3(C * B)) + f3(D * E), den = e * (A * e + f3(B)) + f3(D * F);
+        e = divv(num, den) - f3(E / F);
+        float white = ((W * (A * W + C * B) + D * E) / (W * (A * W + B) + D * F)) - E / F;
+        e = e / white;
+    }
+    e = f3(gamma_correct(e.x), gamma_correct(e.y), gamma_correct(e.z));
+    const double r = 255.999 * e.x, g = 255.999 * e.y, b = 255.999 * e.z;
+    const bool ok = a != 0;
+    out[3 * p] = ok && r == r ? (unsigned char)(int)r : 0;
+    out[3 * p + 1] = ok && g == g ? (unsigned char)(int)g : 0;
+    out[3 * p + 2] = ok && b == b ? (unsigned char)(int)b : 0;
+}
+
 /* ray generation alone, SoA planes of n = npix (ptr_generate_rays) */
 __global__ void __launch_bounds__(TPB) k_raygen_only(DCamera cam, PassParams prm, int sample, float *o_out, float *d_out, float *w_out) {
     int p = blockIdx.x * TPB + threadIdx.x;
@@ -869,6 +903,39 @@ int ptr_film_read(PtrContext *ctx, float *we_rgb, double *acc_weight, int64_t *s
     if (we_rgb) HIPCHK(hipMemcpy(we_rgb, ctx->we, 3 * sizeof(float) * ctx->npix, hipMemcpyDeviceToHost));
     if (acc_weight) HIPCHK(hipMemcpy(acc_weight, ctx->acc, sizeof(double) * ctx->npix, hipMemcpyDeviceToHost));
     if (samples) HIPCHK(hipMemcpy(samples, ctx->samples, sizeof(int64_t) * ctx->npix, hipMemcpyDeviceToHost));
+    return PTR_OK;
+}
+
+int ptr_film_write(PtrContext *ctx, const float *we_rgb, const double *acc_weight, const int64_t *samples, int64_t next_sample) {
+    int rc = ctx_use(ctx);
+    if (rc) return rc;
+    if (!ctx->has_film) return set_err(PTR_ERR_STATE, "no film");
+    if (!we_rgb || !acc_weight || !samples) return set_err(PTR_ERR_INVALID, "null accumulator array");
+    if (next_sample < 0) next_sample = samples[0];
+    if (next_sample < 0 || next_sample > 0x7fffffff) return set_err(PTR_ERR_INVALID, "sample index out of range");
+    if ((rc = sync_all(ctx))) return rc;
+    HIPCHK(hipMemcpy(ctx->we, we_rgb, 3 * sizeof(float) * ctx->npix, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->acc, acc_weight, sizeof(double) * ctx->npix, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->samples, samples, sizeof(int64_t) * ctx->npix, hipMemcpyHostToDevice));
+    ctx->sample_cursor = (int)next_sample;
+    return PTR_OK;
+}
+
+int ptr_film_rgb8(PtrContext *ctx, float exposure, int algorithm, unsigned char *rgb) {
+    int rc = ctx_use(ctx);
+    if (rc) return rc;
+    if (!ctx->has_film) return set_err(PTR_ERR_STATE, "no film");
+    if (!rgb) return set_err(PTR_ERR_INVALID, "null output");
+    if (algorithm < PTR_TONEMAP_REINHARD || algorithm > PTR_TONEMAP_NAUGHTYDOG) return set_err(PTR_ERR_INVALID, "unknown tone mapping algorithm");
+    if ((rc = sync_all(ctx))) return rc;
+    unsigned char *d = nullptr;
+    HIPCHK(hipMalloc((void **)&d, 3 * (size_t)ctx->npix));
+    hipLaunchKernelGGL(k_tonemap, dim3(nblocks(ctx->npix)), dim3(TPB), 0, ctx->stream, (const float *)ctx->we, (const double *)ctx->acc, ctx->npix, exposure,
+                       algorithm, d);
+    hipError_t e = hipMemcpyAsync(rgb, d, 3 * (size_t)ctx->npix, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return set_err(PTR_ERR_HIP, hipGetErrorString(e));
     return PTR_OK;
 }
 

@@ -177,6 +177,19 @@ void SetIntegrator(int ptr_li_id);
 /* copy the device accumulators into image->pixels (the reference reads managed memory) */
 void ImageSync(Image *image);
 
+/* ---- film output: camera.h:38-42, ppm.h:8-13, util.h:41 (host/pt_image.cpp) -----------------------
+ * The per-pixel tone map runs on the device (ptr_film_rgb8). */
+void ImageWrite(Image *image, const char *path, Float exposure, ToneMapAlgorithm algorithm);
+void ImageStats(Image *image);
+void ImageRGB8(Image *image, Float exposure, ToneMapAlgorithm algorithm, unsigned char *data);
+bool ImageWritePPM(Image *image, const char *path, Float exposure, ToneMapAlgorithm algorithm);
+bool PPMRead(const char *path, unsigned char **values, int &width, int &height);
+void ConvertPPMtoPNG(const char *path, const char *out);
+bool EncodePNG(const unsigned char *rgb, int width, int height, bool flip, std::vector<unsigned char> &png);
+/* checkpoint / resume of the float accumulators (replaces the temp.ppm backup, graphy.cpp:11,63) */
+bool ImageCheckpoint(Image *image, const char *path);
+bool ImageResume(Image *image, Aggregator *scene, const char *path);
+
 /* ---- flattening (what PrepareSceneForRendering hands to ptr_scene_upload) -------------------- */
 struct FlatSceneHolder;
 /* Build the flat description of everything inserted since BeginScene.  The holder owns all

@@ -82,6 +82,41 @@ class Renderer:
         sh = (self.height, self.width)
         return we.reshape(sh + (3,)), acc.reshape(sh), smp.reshape(sh)
 
+    def film_write(self, we, acc, samples, next_sample=-1):
+        """Restore saved accumulators (ptr_film_write); rendering continues at next_sample."""
+        n = self.width * self.height
+        we = np.ascontiguousarray(we, dtype=np.float32).reshape(n, 3)
+        acc = np.ascontiguousarray(acc, dtype=np.float64).reshape(n)
+        samples = np.ascontiguousarray(samples, dtype=np.int64).reshape(n)
+        capi.check(capi.hip().ptr_film_write(self._ctx, we.ctypes.data, acc.ctypes.data, samples.ctypes.data, int(next_sample)))
+
+    def rgb8(self, exposure=2.0, algorithm=capi.TONEMAP_EXPONENTIAL):
+        """GetPixelRGB over the film on the device (camera.cpp:36-51): uint8 [h, w, 3], row 0 = bottom
+        of the frame like the Pixel array.  Defaults are render()'s (main.cpp:1185)."""
+        out = np.empty((self.height, self.width, 3), dtype=np.uint8)
+        capi.check(capi.hip().ptr_film_rgb8(self._ctx, float(exposure), int(algorithm), out.ctypes.data))
+        return out
+
+    def save(self, path, exposure=2.0, algorithm=capi.TONEMAP_EXPONENTIAL):
+        """ImageWrite (camera.cpp:53-85): PNG, or binary PPM when the path ends in .ppm (ppm.cpp:4-32)."""
+        rc = capi.host().pth_image_write(self._ctx, self.width, self.height, str(path).encode(), float(exposure), int(algorithm))
+        if rc == 1:
+            raise capi.PtrError(rc, capi.hip().ptr_last_error().decode("utf-8", "replace"))
+        if rc:
+            raise OSError("could not write %s (code %d)" % (path, rc))
+
+    def checkpoint(self, path):
+        """Float accumulators to one .npz-like file (np.savez): resume with Renderer.resume."""
+        we, acc, smp = self.film()
+        with open(path, "wb") as f:
+            np.savez(f, we=we, acc=acc, samples=smp)
+
+    def resume(self, path, next_sample=-1):
+        with np.load(path, allow_pickle=False) as z:
+            if z["acc"].shape != (self.height, self.width):
+                raise ValueError("checkpoint is %s, film is %s" % (z["acc"].shape, (self.height, self.width)))
+            self.film_write(z["we"], z["acc"], z["samples"], next_sample)
+
     def film_device_ptrs(self):
         a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
         capi.check(capi.hip().ptr_film_device_ptrs(self._ctx, C.byref(a), C.byref(b), C.byref(c)))

@@ -19,7 +19,7 @@ HEADER = os.path.join(ROOT, "include", "ptr_api.h")
 def declared_functions():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(ptr_[a-z_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(ptr_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_header_declares_expected_entry_points():
@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared_functions():
         assert getattr(lib, name) is not None
     out = subprocess.run(["nm", "-D", "--defined-only", capi.HIP_LIB], stdout=subprocess.PIPE, text=True, check=True).stdout
-    exported = set(re.findall(r" T (ptr_[a-z_]+)", out))
+    exported = set(re.findall(r" T (ptr_[a-z0-9_]+)", out))
     assert set(declared_functions()) <= exported
 
 
