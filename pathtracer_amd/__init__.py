@@ -4,7 +4,7 @@ csrc/   HIP kernels (gfx950) + the C-ABI of include/ptr_api.h  -> lib/libptr_hip
 host/   C++ mirror of the reference's scene-description API       -> lib/libpt_host.so
 capi    ctypes view of both; scene / render: Python drivers over the C-ABI
 """
-from . import capi  # noqa: F401
+from . import assets, capi  # noqa: F401
 from .capi import (LI_DIRECT, LI_PATH, LI_PATHSAMPLED, LI_VOLPATH, TONEMAP_EXPONENTIAL, TONEMAP_NAUGHTYDOG,  # noqa: F401
                    TONEMAP_REINHARD, PtrError)  # noqa: F401
 from .render import Renderer  # noqa: F401

@@ -130,6 +130,25 @@ HOST_SIGNATURES = {
     "pth_png_encode": (C.c_long, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_long]),
     "pth_image_write": (C.c_int, [CTX, C.c_int, C.c_int, C.c_char_p, C.c_float, C.c_int]),
     "pth_ppm_read": (C.c_int, [C.c_char_p, C.c_void_p, C.c_long, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "pth_parse_double": (C.c_int, [C.c_char_p, C.POINTER(C.c_float)]),
+    "pth_obj_load": (C.c_void_p, [C.c_char_p, C.c_int]),
+    "pth_obj_count": (C.c_int, [C.c_void_p]),
+    "pth_obj_mesh": (None, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(fptr), C.POINTER(fptr), C.POINTER(fptr), C.POINTER(iptr)]),
+    "pth_obj_mtl": (C.c_long, [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_long]),
+    "pth_obj_free": (None, [C.c_void_p]),
+    "pth_mtl_load": (C.c_void_p, [C.c_char_p, C.c_char_p, C.c_int]),
+    "pth_mtl_count": (C.c_int, [C.c_void_p]),
+    "pth_mtl_name": (C.c_long, [C.c_void_p, C.c_int, C.c_char_p, C.c_long]),
+    "pth_mtl_find": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "pth_mtl_value": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_long]),
+    "pth_mtl_spectrum": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, fptr]),
+    "pth_mtl_material": (None, [C.c_void_p, C.c_int, C.POINTER(C.c_int), fptr]),
+    "pth_mtl_free": (None, [C.c_void_p]),
+    "pth_image_load": (C.c_void_p, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(fptr)]),
+    "pth_image_free": (None, [C.c_void_p]),
+    "pth_particles_load": (C.c_void_p, [C.c_char_p, C.c_char_p]),
+    "pth_particles_get": (fptr, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "pth_particles_free": (None, [C.c_void_p]),
     "pth_camera_config": (None, [fptr, fptr, fptr, f32, f32, f32, C.POINTER(PtrCamera)]),
 }
 

@@ -1,0 +1,865 @@
+/*
+ * pt_loaders.cpp — OBJ / MTL / particle / texture-image ingest (see pt_loaders.h).  Written from the
+ * behaviour of the reference's parsers, including the parts that matter for what ends up in the
+ * scene: the number grammar of ParseDouble (mtl.cpp:41-154), first-use vertex compaction per
+ * sub-mesh (obj_loader.cpp:172-258), the rule that any non-face line closes a sub-mesh
+ * (obj_loader.cpp:320-323), quad fan order (obj_loader.cpp:413-419) and the token stepping of the
+ * MTL value list (mtl.cpp:205-221).
+ *
+ * Argument evaluation order.  The reference reads a vector as
+ *     Flip(vec3f(ParseFloat(t), ParseFloat(t), ParseFloat(t)))            (obj_loader.cpp:134-140)
+ * and is built with g++, which evaluates the three calls right to left: the first number of the line
+ * lands in z, Flip swaps it back, and "v 1 2 3" is (1, 2, 3).  Here the three reads are sequenced
+ * explicitly, so the result does not depend on the compiler.
+ */
+#include "pt_loaders.h"
+#include <cstdlib>
+#include <fstream>
+#include <sstream>
+#include <zlib.h>
+
+/* ---- numbers ------------------------------------------------------------------------------------------ */
+static inline bool is_digit(char c) { return (unsigned)(c - '0') < 10u; }
+
+bool ParseDouble(const char *s, const char *s_end, Float *result) {
+    if (s >= s_end) return false;
+    const char *c = s;
+    int sign = 1;
+    if (*c == '+' || *c == '-') { sign = (*c == '-') ? -1 : 1; ++c; }
+    else if (!is_digit(*c)) return false;
+
+    double mantissa = 0.0;
+    int ndigits = 0;
+    for (; c != s_end && is_digit(*c); ++c, ++ndigits) { mantissa *= 10; mantissa += (int)(*c - '0'); }
+    if (ndigits == 0) return false;
+
+    int exponent = 0;
+    bool have_exp = false;
+    if (c != s_end) {
+        if (*c == '.') {
+            ++c;
+            /* digit k after the point adds d * 10^-k: table up to 1e-7, pow beyond (mtl.cpp:101-108) */
+            static const double tenth[] = {1.0, 0.1, 0.01, 0.001, 0.0001, 0.00001, 0.000001, 0.0000001};
+            for (int k = 1; c != s_end && is_digit(*c); ++c, ++k)
+                mantissa += (int)(*c - '0') * (k < 8 ? tenth[k] : std::pow(10.0, -k));
+            have_exp = c != s_end && (*c == 'e' || *c == 'E');
+        } else if (*c == 'e' || *c == 'E') have_exp = true;
+    }
+    if (have_exp) {
+        ++c;
+        int esign = 1;
+        if (c != s_end && (*c == '+' || *c == '-')) { esign = (*c == '-') ? -1 : 1; ++c; }
+        else if (!is_digit(*c)) return false; /* (reads the terminator when the token ends in 'e', as the reference does) */
+        int n = 0;
+        for (; c != s_end && is_digit(*c); ++c, ++n) { exponent *= 10; exponent += (int)(*c - '0'); }
+        exponent *= esign;
+        if (n == 0) return false;
+    }
+    /* 10^e = 5^e * 2^e; the double is narrowed to Float on assignment */
+    *result = sign * (exponent ? std::ldexp(mantissa * std::pow(5.0, exponent), exponent) : mantissa);
+    return true;
+}
+
+Float ParseFloat(const char **token) {
+    (*token) += strspn(*token, " \t");
+    const char *end = (*token) + strcspn(*token, " \t\r");
+    Float val = 0;
+    ParseDouble(*token, end, &val);
+    *token = end;
+    return val;
+}
+void ParseV3(vec3f *v, const char **token) {
+    Float a = ParseFloat(token);
+    Float b = ParseFloat(token);
+    Float c = ParseFloat(token);
+    *v = vec3f(a, b, c);
+}
+void ParseV2(vec2f *v, const char **token) {
+    Float a = ParseFloat(token);
+    Float b = ParseFloat(token);
+    *v = vec2f(a, b);
+}
+
+/* a line ends at \n, \r\n or a lone \r; end of file ends the last line (obj_loader.cpp:105-122) */
+std::istream &GetLine(std::istream &is, std::string &t) {
+    t.clear();
+    std::istream::sentry guard(is, true);
+    if (!guard) return is;
+    std::streambuf *sb = is.rdbuf();
+    while (true) {
+        int ch = sb->sbumpc();
+        if (ch == '\n') break;
+        if (ch == '\r') { if (sb->sgetc() == '\n') sb->sbumpc(); break; }
+        if (ch == EOF) { if (t.empty()) is.setstate(std::ios::eofbit); break; }
+        t.push_back((char)ch);
+    }
+    return is;
+}
+/* next non-empty, non-comment line, leading blanks skipped; false at end of file */
+static bool next_payload_line(std::istream &is, std::string &buf, const char **token) {
+    while (is.peek() != -1) {
+        GetLine(is, buf);
+        if (!buf.empty() && buf.back() == '\n') buf.pop_back();
+        if (!buf.empty() && buf.back() == '\r') buf.pop_back();
+        if (buf.empty()) continue;
+        const char *t = buf.c_str();
+        t += strspn(t, " \t");
+        if (t[0] == '\0' || t[0] == '#') continue;
+        *token = t;
+        return true;
+    }
+    return false;
+}
+static inline bool is_blank(char c) { return c == ' ' || c == '\t'; }
+static inline bool ends_line(char c) { return c == '\r' || c == '\n' || c == '\0'; }
+
+/* ---- OBJ ------------------------------------------------------------------------------------------------ */
+namespace {
+struct Corner { int v, vt, vn; }; /* indices into the file-wide lists, -1 = absent */
+
+/* 1-based -> 0-based, negative = relative to the current list end, 0 is invalid (obj_loader.cpp:26-47) */
+bool resolve_index(int idx, int n, int *out) {
+    if (idx > 0) { *out = idx - 1; return true; }
+    if (idx < 0) { *out = n + idx; return true; }
+    return false;
+}
+/* "i", "i/j", "i//k", "i/j/k" (obj_loader.cpp:49-101) */
+bool parse_corner(const char **tok, int nv, int nvn, int nvt, Corner *out) {
+    Corner c = {-1, -1, -1};
+    if (!resolve_index(atoi(*tok), nv, &c.v)) return false;
+    *tok += strcspn(*tok, "/ \t\r");
+    if ((*tok)[0] != '/') { *out = c; return true; }
+    ++*tok;
+    if ((*tok)[0] == '/') {
+        ++*tok;
+        if (!resolve_index(atoi(*tok), nvn, &c.vn)) return false;
+        *tok += strcspn(*tok, "/ \t\r");
+        *out = c;
+        return true;
+    }
+    if (!resolve_index(atoi(*tok), nvt, &c.vt)) return false;
+    *tok += strcspn(*tok, "/ \t\r");
+    if ((*tok)[0] != '/') { *out = c; return true; }
+    ++*tok;
+    if (!resolve_index(atoi(*tok), nvn, &c.vn)) return false;
+    *tok += strcspn(*tok, "/ \t\r");
+    *out = c;
+    return true;
+}
+
+template <typename T> T *clone_array(const std::vector<T> &v) {
+    if (v.empty()) return nullptr;
+    T *p = new T[v.size()];
+    for (size_t i = 0; i < v.size(); i++) p[i] = v[i];
+    return p;
+}
+
+/* One sub-mesh out of the corners gathered so far: positions / normals / uvs are renumbered in order of
+ * first use, indices become (position, normal, uv) triples per corner (obj_loader.cpp:172-258). */
+void close_mesh(ParsedMesh *mesh, const std::vector<vec3f> &v, const std::vector<vec3f> &vn, const std::vector<vec2f> &vt,
+                const std::vector<Corner> &corners) {
+    std::vector<int> newV(v.size(), -1), newN(vn.size(), -1), newU(vt.size(), -1);
+    std::vector<Point3f> P;
+    std::vector<Normal3f> N;
+    std::vector<Point2f> U;
+    std::vector<Point3i> I(corners.size());
+    for (size_t i = 0; i < corners.size(); i++) {
+        const Corner &c = corners[i];
+        if (c.v < 0 || c.v >= (int)v.size() || c.vn >= (int)vn.size() || c.vt >= (int)vt.size()) {
+            printf("OBJ: face refers to an element that is not in the file (the reference reads out of bounds here)\n");
+            exit(1);
+        }
+        if (newV[c.v] < 0) { newV[c.v] = (int)P.size(); P.push_back(Point3f(v[c.v].x, v[c.v].y, v[c.v].z)); }
+        if (c.vn > -1 && newN[c.vn] < 0) { newN[c.vn] = (int)N.size(); N.push_back(vn[c.vn]); }
+        if (c.vt > -1 && newU[c.vt] < 0) { newU[c.vt] = (int)U.size(); U.push_back(Point2f(vt[c.vt].x, vt[c.vt].y)); }
+        I[i] = Point3i(newV[c.v], c.vn > -1 ? newN[c.vn] : -1, c.vt > -1 ? newU[c.vt] : -1);
+    }
+    mesh->p = clone_array(P);
+    mesh->n = clone_array(N);
+    mesh->uv = clone_array(U);
+    mesh->indices = clone_array(I);
+    mesh->nTriangles = (int)(corners.size() / 3);
+    mesh->nVertices = (int)P.size();
+    mesh->nNormals = (int)N.size();
+    mesh->nUvs = (int)U.size();
+}
+
+ParsedMesh *blank_mesh() {
+    ParsedMesh *m = new ParsedMesh();
+    m->p = nullptr; m->n = nullptr; m->s = nullptr; m->uv = nullptr; m->indices = nullptr;
+    m->nTriangles = m->nVertices = m->nUvs = m->nNormals = 0;
+    m->toWorld = Translate(0, 0, 0);
+    return m;
+}
+} // namespace
+
+void FreeParsedMesh(ParsedMesh *m) {
+    if (!m) return;
+    delete[] m->p; delete[] m->n; delete[] m->s; delete[] m->uv; delete[] m->indices;
+    delete m;
+}
+
+ParsedMesh *LoadObjOnly(const char *path) {
+    std::vector<MeshMtl> mtls;
+    std::vector<ParsedMesh *> *meshes = LoadObj(path, &mtls, false);
+    ParsedMesh *mesh = meshes->empty() ? nullptr : meshes->at(0); /* the reference's at(0) throws on a file without faces */
+    delete meshes;
+    return mesh;
+}
+
+std::vector<ParsedMesh *> *LoadObj(const char *path, std::vector<MeshMtl> *mtls, bool split_mesh) {
+    std::vector<ParsedMesh *> *meshes = new std::vector<ParsedMesh *>();
+    printf("Attempting to parse %s\n", path);
+    std::ifstream ifs(path);
+    if (!ifs) {
+        printf("Could not open file %s\n", path);
+        return meshes;
+    }
+    std::vector<vec3f> v, vn;
+    std::vector<vec2f> vt;
+    std::vector<Corner> corners;
+    ParsedMesh *open_mesh = nullptr; /* sub-mesh being gathered */
+    std::string mtl_file, mtl_name, line;
+    const char *tok = nullptr;
+    clock_t start = clock();
+
+    while (next_payload_line(ifs, line, &tok)) {
+        /* any line that does not start with 'f' ends the sub-mesh (the test is on the first character only) */
+        if (tok[0] != 'f' && open_mesh && split_mesh) {
+            close_mesh(open_mesh, v, vn, vt, corners);
+            open_mesh = nullptr;
+        }
+        /* "o name": the name is skipped and the rest of the line goes through the same tests, so an object
+         * called "v 1 2 3" is also a vertex (obj_loader.cpp:325-331 has no `continue`) */
+        if (tok[0] == 'o' && is_blank(tok[1])) tok += 2;
+        const bool is_face = tok[0] == 'f' && is_blank(tok[1]);
+        if (tok[0] == 'v' && is_blank(tok[1])) {
+            tok += 2;
+            vec3f p;
+            ParseV3(&p, &tok);
+            v.push_back(p);
+        } else if (tok[0] == 'v' && tok[1] == 'n' && is_blank(tok[2])) {
+            tok += 3;
+            vec3f n;
+            ParseV3(&n, &tok);
+            vn.push_back(n);
+        } else if (tok[0] == 'v' && tok[1] == 't' && is_blank(tok[2])) {
+            tok += 3;
+            vec2f uv;
+            ParseV2(&uv, &tok);
+            vt.push_back(uv);
+        } else if (strncmp(tok, "mtllib", 6) == 0 && is_blank(tok[6])) {
+            mtl_file = std::string(tok + 7);
+        } else if (strncmp(tok, "usemtl", 6) == 0 && is_blank(tok[6])) {
+            mtl_name = std::string(tok + 7);
+        } else if (is_face) {
+            if (!open_mesh) {
+                open_mesh = blank_mesh();
+                meshes->push_back(open_mesh);
+                MeshMtl m;
+                m.file = mtl_file;
+                m.name = mtl_name;
+                mtls->push_back(m);
+                corners.clear();
+            }
+            tok += 2;
+            tok += strspn(tok, " \t");
+            Corner face[4];
+            int nc = 0;
+            while (!ends_line(tok[0])) {
+                Corner c;
+                if (!parse_corner(&tok, (int)v.size(), (int)vn.size(), (int)vt.size(), &c)) {
+                    printf("Failed parsing face\n");
+                    break;
+                }
+                tok += strspn(tok, " \t\r");
+                if (nc >= 4) {
+                    printf("Error: Not a supported face description\n");
+                    exit(0);
+                }
+                face[nc++] = c;
+            }
+            if (nc == 3) {
+                corners.insert(corners.end(), face, face + 3);
+            } else if (nc == 4) { /* fan: (0 1 2) (0 2 3) */
+                const Corner quad[6] = {face[0], face[1], face[2], face[0], face[2], face[3]};
+                corners.insert(corners.end(), quad, quad + 6);
+            } else {
+                printf("Warning unsupported face with %d vertices\n", nc);
+            }
+        }
+        /* 'o', 'g', 's' and anything else: no state of their own */
+    }
+    if (open_mesh) close_mesh(open_mesh, v, vn, vt, corners);
+    printf("Took %g seconds, #v [%d] #vn [%d] #vt [%d]. Decomposed in %d meshe(s)\n", (double)(clock() - start) / CLOCKS_PER_SEC, (int)v.size(),
+           (int)vn.size(), (int)vt.size(), (int)meshes->size());
+    return meshes;
+}
+
+/* obj_loader.cpp:445-521: deep copy; flip_x mirrors positions about the vertex centroid */
+ParsedMesh *DuplicateMesh(ParsedMesh *mesh, MeshProperties *props) {
+    if (!mesh) return nullptr;
+    ParsedMesh *d = blank_mesh();
+    d->toWorld = mesh->toWorld;
+    d->nVertices = mesh->nVertices; d->nTriangles = mesh->nTriangles; d->nUvs = mesh->nUvs; d->nNormals = mesh->nNormals;
+    vec3f center;
+    if (mesh->p) {
+        Float w = 0.f;
+        for (int i = 0; i < mesh->nVertices; i++) {
+            center = center + vec3f(mesh->p[i].x, mesh->p[i].y, mesh->p[i].z);
+            w += 1.f;
+        }
+        Float invW = 1.f / w;
+        center = center * invW;
+        d->p = new Point3f[mesh->nVertices];
+        for (int i = 0; i < mesh->nVertices; i++) {
+            Point3f p = mesh->p[i];
+            if (props && props->flip_x) {
+                vec3f op = vec3f(p.x, p.y, p.z) - center;
+                vec3f wp(-op.x, op.y, op.z);
+                p = Point3f(wp.x + center.x, wp.y + center.y, wp.z + center.z);
+            }
+            d->p[i] = p;
+        }
+    }
+    if (mesh->uv) { d->uv = new Point2f[mesh->nUvs]; for (int i = 0; i < mesh->nUvs; i++) d->uv[i] = mesh->uv[i]; }
+    if (mesh->n) { d->n = new Normal3f[mesh->nNormals]; for (int i = 0; i < mesh->nNormals; i++) d->n[i] = mesh->n[i]; }
+    if (mesh->indices) {
+        d->indices = new Point3i[(size_t)mesh->nTriangles * 3];
+        for (int i = 0; i < mesh->nTriangles * 3; i++) d->indices[i] = mesh->indices[i];
+    }
+    return d;
+}
+
+/* ---- MTL ------------------------------------------------------------------------------------------------ */
+namespace {
+const char *const kMtlKeys[13] = {"Ka", "Kd", "Ks", "Tf", "Ns", "illum", "map_Ka", "map_Kd", "map_Ks", "d", "Ke", "Ni", "map_Bump"};
+const bool kMtlKeyNumeric[13] = {true, true, true, true, true, true, false, false, false, true, true, true, false};
+
+bool starts_with(const std::string &s, const char *prefix) { return s.compare(0, strlen(prefix), prefix) == 0; }
+inline char at(const std::string &s, size_t i) { return i < s.size() ? s[i] : '\0'; }
+inline bool is_sep(char c) { return c == ' ' || c == '\n' || c == '\r'; }
+
+/* the word that starts at or after `pos`; *last when nothing is left (mtl.cpp:162-190) */
+std::string word_from(const std::string &s, size_t pos, bool *last) {
+    *last = true;
+    while (pos < s.size() && is_sep(s[pos])) pos++;
+    if (pos >= s.size()) return std::string();
+    size_t end = pos;
+    while (end < s.size() && !is_sep(s[end])) end++;
+    char stop = at(s, end);
+    *last = (stop == '\n' || stop == '\r');
+    return s.substr(pos, end - pos);
+}
+/* Values of "key v0 v1 ...".  The cursor advances by len(value) + 1 from the end of the key, not from
+ * where the value was found (mtl.cpp:214-220): with single blanks that is the next value, with runs of
+ * blanks or tabs the following reads start inside the previous value.  Kept, since it decides what a
+ * given file turns into. */
+std::vector<std::string> key_values(const std::string &line, size_t key_len) {
+    std::vector<std::string> out;
+    size_t cur = key_len;
+    bool last = false;
+    while (!last) {
+        std::string w = word_from(line, cur, &last);
+        if (!w.empty()) { out.push_back(w); cur += w.size() + 1; }
+    }
+    return out;
+}
+} // namespace
+
+bool MTLParse(const char *path, std::vector<MTL *> *materials, const char *basedir) {
+    if (!materials) {
+        printf("Invalid materials pointer for MTL parsing\n");
+        return false;
+    }
+    std::string filename = std::string(basedir) + std::string(path);
+    std::ifstream in(filename.c_str());
+    if (!in.is_open()) {
+        printf("Could not open file: %s\n", path);
+        return false;
+    }
+    MTL *cur = nullptr;
+    bool in_material = false;
+    std::string raw;
+    while (std::getline(in, raw)) { /* '\n' only: a lone '\r' does not end a line here, unlike the OBJ reader */
+        if (!raw.empty() && raw.back() == '\n') raw.pop_back();
+        if (!raw.empty() && raw.back() == '\r') raw.pop_back();
+        if (raw.empty()) continue;
+        const char *t = raw.c_str();
+        t += strspn(t, " \t");
+        if (t[0] == '#') continue;
+        std::string line(t);
+        if (line.empty()) continue;
+        if (starts_with(line, "newmtl")) {
+            bool last;
+            cur = new MTL;
+            cur->mtlname = word_from(line, 6, &last);
+            cur->basedir = std::string(basedir);
+            materials->push_back(cur);
+            in_material = true;
+        } else if (in_material) {
+            int k = 0;
+            while (k < 13 && !starts_with(line, kMtlKeys[k])) k++; /* first key that prefixes the line, in table order */
+            if (k == 13) {
+                printf("Could not find token for line: %s\n", line.c_str());
+                in_material = false; /* properties are ignored until the next newmtl */
+            } else {
+                cur->data[kMtlKeys[k]] = key_values(line, strlen(kMtlKeys[k]));
+            }
+        }
+    }
+    return true;
+}
+
+std::string MTLGetValue(const char *property, MTL *mtl, bool &found) {
+    std::string out;
+    found = false;
+    if (!mtl) return out;
+    auto it = mtl->data.find(property);
+    if (it == mtl->data.end()) return out;
+    found = true;
+    for (size_t i = 0; i < it->second.size(); i++) {
+        if (i) out += " ";
+        out += it->second[i];
+    }
+    return out;
+}
+
+Spectrum MTLGetSpectrum(const char *property, MTL *mtl, bool &found) {
+    Spectrum e(0);
+    found = false;
+    if (!mtl) return e;
+    auto it = mtl->data.find(property);
+    if (it == mtl->data.end()) return e;
+    found = true;
+    bool numeric = false;
+    for (int k = 0; k < 13; k++)
+        if (strcmp(property, kMtlKeys[k]) == 0) numeric = kMtlKeyNumeric[k];
+    if (!numeric) {
+        printf("Warning: Query for non numeric property (%s)\n", property);
+        return e;
+    }
+    const std::vector<std::string> &vals = it->second;
+    for (size_t c = 0; c < 3 && c < vals.size(); c++) { /* stops at the first value that is not a number */
+        Float x = 0;
+        if (!ParseDouble(vals[c].c_str(), vals[c].c_str() + vals[c].size(), &x)) break;
+        e[(int)c] = x;
+    }
+    return e;
+}
+
+MTL *MTLFindMaterial(const char *name, std::vector<MTL *> *materials) {
+    for (MTL *m : *materials)
+        if (m->mtlname == name) return m;
+    printf("Warning: Did not find material (%s)\n", name);
+    return materials->at(0);
+}
+
+/* one parse per sub-mesh descriptor, so a library used by n sub-meshes is listed n times; lookups take
+ * the first entry of a name (mtl.cpp:366-379) */
+bool MTLParseAll(std::vector<MTL *> *materials, std::vector<MeshMtl> *desc, const char *basedir) {
+    bool ok = true;
+    if (desc)
+        for (size_t i = 0; i < desc->size() && ok; i++) ok &= MTLParse((*desc)[i].file.c_str(), materials, basedir);
+    return ok;
+}
+
+/* scene.cpp:484-577: Ke -> light; Kd + Ks (maps win over colours) -> plastic, roughness 0.03; one of the
+ * two -> matte when it was Ks, the "broken uber" otherwise; neither -> grey matte */
+MaterialDescriptor MakeMTLMaterial(MTL *mtl) {
+    bool found = false;
+    Spectrum L = MTLGetSpectrum("Ke", mtl, found);
+    const bool black = L.x == 0 && L.y == 0 && L.z == 0;
+    if (!black && found) return MakeEmissive(L);
+
+    MaterialDescriptor desc;
+    memset((void *)&desc, 0, sizeof(desc));
+    bool hasKd = false, hasKdMap = false, hasKs = false, hasKsMap = false;
+    Spectrum kd = MTLGetSpectrum("Kd", mtl, hasKd);
+    std::string kdMap = MTLGetValue("map_Kd", mtl, hasKdMap);
+    Spectrum ks = MTLGetSpectrum("Ks", mtl, hasKs);
+    std::string ksMap = MTLGetValue("map_Ks", mtl, hasKsMap);
+    int i = 0;
+    bool kd_colour = hasKd, ks_colour = hasKs;
+    if (hasKdMap) {
+        ImageData *img = LoadTextureImageData((mtl->basedir + kdMap).c_str());
+        if (img) { desc.textures[i++] = MakeTexture(img); kd_colour = false; printf(" * Got Kd map\n"); }
+        else hasKdMap = false;
+    }
+    if (kd_colour) desc.textures[i++] = MakeTexture(kd);
+    if (hasKsMap) {
+        ImageData *img = LoadTextureImageData((mtl->basedir + ksMap).c_str());
+        if (img) { desc.textures[i++] = MakeTexture(img); ks_colour = false; printf(" * Got Ks map\n"); }
+        else hasKsMap = false;
+    }
+    if (ks_colour) desc.textures[i++] = MakeTexture(ks);
+
+    if (i == 2) {
+        Float rough = 0.03;
+        desc.textures[i++] = MakeTexture(rough);
+        desc.type = MaterialType::Plastic;
+    } else if (i == 1) {
+        if (hasKs || hasKsMap) {
+            Float sigma = 0;
+            desc.textures[i++] = MakeTexture(sigma);
+            desc.type = MaterialType::Matte;
+        } else {
+            printf("Warning: broken uber material\n");
+            desc = MakeUberMaterial(Spectrum(0.001), ks, Spectrum(0), Spectrum(0), 0, 0, Spectrum(1), 1.5f);
+        }
+    } else {
+        printf("Warning: Could not make material for MTL\n");
+        desc.textures[i++] = MakeTexture((Float)0.45);
+        desc.textures[i++] = MakeTexture((Float)0.);
+        desc.type = MaterialType::Matte;
+    }
+    if (desc.specs_taken == 0) desc.specs_taken = i; /* slots filled above (the uber fallback brings its own count) */
+    return desc;
+}
+
+/* ---- texture images ------------------------------------------------------------------------------------- */
+namespace {
+bool read_file(const char *path, std::vector<unsigned char> &out) {
+    FILE *fp = fopen(path, "rb");
+    if (!fp) return false;
+    unsigned char buf[1 << 16];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, fp)) > 0) out.insert(out.end(), buf, buf + n);
+    fclose(fp);
+    return true;
+}
+uint32_t be32(const unsigned char *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+
+/* 8-bit, non-interlaced PNG -> rows top-down, `nn` interleaved channels (what stbi_load(..., 0) returns) */
+bool decode_png(const std::vector<unsigned char> &f, std::vector<unsigned char> &px, int &w, int &h, int &nn) {
+    static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    if (f.size() < 8 + 25 || memcmp(f.data(), sig, 8) != 0) return false;
+    std::vector<unsigned char> idat, plte;
+    int ctype = -1;
+    size_t at = 8;
+    bool end = false;
+    while (!end && at + 12 <= f.size()) {
+        uint32_t len = be32(&f[at]);
+        const unsigned char *tag = &f[at + 4], *body = &f[at + 8];
+        if (at + 12 + (size_t)len > f.size()) return false;
+        if (crc32(0L, tag, (uInt)(len + 4)) != be32(body + len)) return false;
+        if (memcmp(tag, "IHDR", 4) == 0) {
+            if (len != 13) return false;
+            w = (int)be32(body); h = (int)be32(body + 4);
+            ctype = body[9];
+            if (body[8] != 8 || body[10] != 0 || body[11] != 0 || body[12] != 0) return false; /* depth 8, no interlace */
+        } else if (memcmp(tag, "PLTE", 4) == 0) plte.assign(body, body + len);
+        else if (memcmp(tag, "IDAT", 4) == 0) idat.insert(idat.end(), body, body + len);
+        else if (memcmp(tag, "IEND", 4) == 0) end = true;
+        at += 12 + (size_t)len;
+    }
+    int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+    if (!end || ch == 0 || w <= 0 || h <= 0 || (int64_t)w * h > (1 << 28)) return false;
+    const size_t stride = (size_t)w * ch;
+    std::vector<unsigned char> raw((stride + 1) * h);
+    uLongf got = (uLongf)raw.size();
+    if (uncompress(raw.data(), &got, idat.data(), (uLong)idat.size()) != Z_OK || got != raw.size()) return false;
+    std::vector<unsigned char> img(stride * h);
+    for (int y = 0; y < h; y++) { /* undo the scanline filters */
+        const unsigned char *in = &raw[(stride + 1) * y + 1];
+        unsigned char *cur = &img[stride * y];
+        const unsigned char *up = y ? &img[stride * (y - 1)] : nullptr;
+        const int ft = raw[(stride + 1) * y];
+        for (size_t x = 0; x < stride; x++) {
+            int a = x >= (size_t)ch ? cur[x - ch] : 0, b = up ? up[x] : 0, c = (up && x >= (size_t)ch) ? up[x - ch] : 0, pred = 0;
+            if (ft == 1) pred = a;
+            else if (ft == 2) pred = b;
+            else if (ft == 3) pred = (a + b) >> 1;
+            else if (ft == 4) {
+                int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+                pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+            } else if (ft != 0) return false;
+            cur[x] = (unsigned char)(in[x] + pred);
+        }
+    }
+    if (ctype == 3) { /* palette -> RGB */
+        px.resize((size_t)w * h * 3);
+        for (size_t i = 0; i < (size_t)w * h; i++) {
+            size_t k = (size_t)img[i] * 3;
+            if (k + 3 > plte.size()) return false;
+            px[3 * i] = plte[k]; px[3 * i + 1] = plte[k + 1]; px[3 * i + 2] = plte[k + 2];
+        }
+        nn = 3;
+    } else {
+        px.swap(img);
+        nn = ch;
+    }
+    return true;
+}
+
+/* binary PGM (P5) / PPM (P6), maxval 255, rows top-down as stored */
+bool decode_pnm(const std::vector<unsigned char> &f, std::vector<unsigned char> &px, int &w, int &h, int &nn) {
+    if (f.size() < 7 || f[0] != 'P' || (f[1] != '5' && f[1] != '6')) return false;
+    nn = f[1] == '6' ? 3 : 1;
+    size_t at = 2;
+    int vals[3], got = 0;
+    while (got < 3 && at < f.size()) {
+        if (f[at] == '#') { while (at < f.size() && f[at] != '\n') at++; continue; }
+        if (isspace(f[at])) { at++; continue; }
+        if (!isdigit(f[at])) return false;
+        int x = 0;
+        while (at < f.size() && isdigit(f[at])) x = x * 10 + (f[at++] - '0');
+        vals[got++] = x;
+    }
+    if (got < 3 || vals[2] != 255 || at >= f.size()) return false;
+    at++; /* the single whitespace byte after maxval */
+    w = vals[0]; h = vals[1];
+    if (w <= 0 || h <= 0 || (int64_t)w * h > (1 << 28)) return false;
+    size_t need = (size_t)w * h * nn;
+    if (f.size() - at < need) return false;
+    px.assign(f.begin() + at, f.begin() + at + need);
+    return true;
+}
+} // namespace
+
+/* texture.cpp:29-64: bytes / 255.f into Spectrum, missing channels stay 0, alpha dropped */
+ImageData *LoadTextureImageData(const char *path) {
+    std::vector<unsigned char> file, px;
+    int nx = 0, ny = 0, nn = 0;
+    if (!read_file(path, file)) {
+        printf("Could not open image %s\n", path);
+        return nullptr;
+    }
+    if (!decode_png(file, px, nx, ny, nn) && !decode_pnm(file, px, nx, ny, nn)) {
+        printf("No decoder for image %s (PNG 8-bit non-interlaced and binary PGM/PPM are supported)\n", path);
+        return nullptr;
+    }
+    ImageData *img = new ImageData();
+    img->data = new Spectrum[(size_t)nx * ny];
+    img->width = nx;
+    img->height = ny;
+    size_t at = 0;
+    for (size_t i = 0; i < (size_t)nx * ny; i++) {
+        Float r = 0, g = 0, b = 0;
+        if (nn > 0) r = px[at++] / 255.f;
+        if (nn > 1) g = px[at++] / 255.f;
+        if (nn > 2) b = px[at++] / 255.f;
+        if (nn == 4) at++;
+        img->data[i] = Spectrum(r, g, b);
+    }
+    img->is_valid = 1;
+    return img;
+}
+
+/* ---- particles (part_loader.cpp) ---------------------------------------------------------------------- */
+enum { PP_INITIALIZED = 1, PP_ALLOCATED = 2 };
+static inline bool fmt_vec(char c) { return c == 'v' || c == 'V'; }
+static inline bool fmt_scalar(char c) { return c == 's' || c == 'S'; }
+
+void PParserInitialize(PParser *parser, const char *format) {
+    parser->format = std::string(format);
+    parser->data = nullptr;
+    parser->state = PP_INITIALIZED;
+}
+
+static void pp_allocate(PParser *parser, int count) {
+    int nv = 0, ns = 0;
+    for (char c : parser->format) {
+        if (fmt_vec(c)) nv++;
+        else if (fmt_scalar(c)) ns++;
+        else printf("Skipping unknown format: %c\n", c);
+    }
+    PParsedData *d = new PParsedData();
+    d->vector_data = nv ? new vec3f *[nv] : nullptr;
+    d->scalar_data = ns ? new Float *[ns] : nullptr;
+    for (int i = 0; i < nv; i++) d->vector_data[i] = new vec3f[count]();
+    for (int i = 0; i < ns; i++) d->scalar_data[i] = new Float[count]();
+    d->nvectors = nv; d->nscalars = ns; d->count = count;
+    parser->data = d;
+    parser->state = PP_ALLOCATED;
+}
+
+/* First payload line: particle count (read as a float, truncated).  Every further line: one value group
+ * per format letter, 'v' = three floats, 's' = one.  True when the file held exactly `count` records
+ * (part_loader.cpp:55-130).  Records beyond `count` are a malformed file: reported instead of written
+ * past the arrays. */
+bool PParserParse(PParser *parser, const char *filename) {
+    if (!(parser->state == PP_INITIALIZED && parser->data == nullptr)) {
+        printf("Invalid parser setup\n");
+        return false;
+    }
+    std::ifstream ifs(filename);
+    if (!ifs) {
+        printf("Failed to open file: %s\n", filename);
+        return false;
+    }
+    std::string line;
+    const char *tok = nullptr;
+    int count = 0, records = 0;
+    bool first = true;
+    clock_t start = clock();
+    while (next_payload_line(ifs, line, &tok)) {
+        if (first) {
+            count = (int)ParseFloat(&tok);
+            printf("Particle count %d\n", count);
+            first = false;
+            if (count < 1) return false;
+            pp_allocate(parser, count);
+            continue;
+        }
+        if (records >= count) {
+            printf("Particle file holds more records than its header says (%d)\n", count);
+            return false;
+        }
+        int vi = 0, si = 0;
+        for (char c : parser->format) {
+            if (fmt_vec(c)) {
+                vec3f v;
+                ParseV3(&v, &tok);
+                parser->data->vector_data[vi++][records] = v;
+            } else if (fmt_scalar(c)) {
+                parser->data->scalar_data[si++][records] = ParseFloat(&tok);
+            }
+        }
+        records++;
+    }
+    if (first) return false;
+    printf("Took %g seconds, #p [%d] #v [%d] #s [%d].\n", (double)(clock() - start) / CLOCKS_PER_SEC, records, parser->data->nvectors,
+           parser->data->nscalars);
+    return records == count;
+}
+
+void PParserCleanup(PParser *parser) {
+    if (parser->state != PP_ALLOCATED) return;
+    PParsedData *d = parser->data;
+    for (int i = 0; i < d->nvectors; i++) delete[] d->vector_data[i];
+    for (int i = 0; i < d->nscalars; i++) delete[] d->scalar_data[i];
+    delete[] d->vector_data;
+    delete[] d->scalar_data;
+    delete d;
+    parser->data = nullptr;
+    parser->state = PP_INITIALIZED;
+}
+
+vec3f *PParserGetVectorPtr(PParser *parser, int index, int *count) {
+    *count = 0;
+    if (parser->state != PP_ALLOCATED || index < 0 || parser->data->nvectors <= index) return nullptr;
+    *count = parser->data->count;
+    return parser->data->vector_data[index];
+}
+Float *PParserGetScalarPtr(PParser *parser, int index, int *count) {
+    *count = 0;
+    if (parser->state != PP_ALLOCATED || index < 0 || parser->data->nscalars <= index) return nullptr;
+    *count = parser->data->count;
+    return parser->data->scalar_data[index];
+}
+
+/* ---- plain-C views for the Python mirror (pathtracer_amd/assets.py) -------------------------------------- */
+namespace {
+struct ObjFile {
+    std::vector<ParsedMesh *> *meshes;
+    std::vector<MeshMtl> mtls;
+};
+struct MtlFile { std::vector<MTL *> mats; };
+long copy_out(const std::string &s, char *buf, long cap) {
+    if (buf && cap > 0) {
+        long n = (long)s.size() < cap - 1 ? (long)s.size() : cap - 1;
+        memcpy(buf, s.data(), n);
+        buf[n] = 0;
+    }
+    return (long)s.size();
+}
+} // namespace
+
+extern "C" {
+int pth_parse_double(const char *s, float *out) { return ParseDouble(s, s + strlen(s), out) ? 1 : 0; }
+
+void *pth_obj_load(const char *path, int split) {
+    ObjFile *f = new ObjFile();
+    f->meshes = LoadObj(path, &f->mtls, split != 0);
+    return f;
+}
+int pth_obj_count(void *h) { return (int)((ObjFile *)h)->meshes->size(); }
+/* counts = {nTriangles, nVertices, nNormals, nUvs}; arrays stay owned by the handle */
+void pth_obj_mesh(void *h, int i, int *counts, const float **p, const float **n, const float **uv, const int **indices) {
+    ParsedMesh *m = ((ObjFile *)h)->meshes->at(i);
+    counts[0] = m->nTriangles; counts[1] = m->nVertices; counts[2] = m->nNormals; counts[3] = m->nUvs;
+    *p = (const float *)m->p; *n = (const float *)m->n; *uv = (const float *)m->uv; *indices = (const int *)m->indices;
+}
+long pth_obj_mtl(void *h, int i, int which, char *buf, long cap) {
+    const MeshMtl &m = ((ObjFile *)h)->mtls.at(i);
+    return copy_out(which ? m.name : m.file, buf, cap);
+}
+void pth_obj_free(void *h) {
+    ObjFile *f = (ObjFile *)h;
+    for (ParsedMesh *m : *f->meshes) FreeParsedMesh(m);
+    delete f->meshes;
+    delete f;
+}
+
+void *pth_mtl_load(const char *file, const char *basedir, int times) {
+    MtlFile *f = new MtlFile();
+    for (int t = 0; t < times; t++)
+        if (!MTLParse(file, &f->mats, basedir)) { delete f; return nullptr; }
+    return f;
+}
+int pth_mtl_count(void *h) { return (int)((MtlFile *)h)->mats.size(); }
+long pth_mtl_name(void *h, int i, char *buf, long cap) { return copy_out(((MtlFile *)h)->mats.at(i)->mtlname, buf, cap); }
+int pth_mtl_find(void *h, const char *name) {
+    MtlFile *f = (MtlFile *)h;
+    MTL *m = MTLFindMaterial(name, &f->mats);
+    for (size_t i = 0; i < f->mats.size(); i++)
+        if (f->mats[i] == m) return (int)i;
+    return -1;
+}
+int pth_mtl_value(void *h, int i, const char *key, char *buf, long cap) {
+    bool found = false;
+    std::string v = MTLGetValue(key, ((MtlFile *)h)->mats.at(i), found);
+    copy_out(v, buf, cap);
+    return found ? 1 : 0;
+}
+int pth_mtl_spectrum(void *h, int i, const char *key, float *rgb) {
+    bool found = false;
+    Spectrum s = MTLGetSpectrum(key, ((MtlFile *)h)->mats.at(i), found);
+    rgb[0] = s.x; rgb[1] = s.y; rgb[2] = s.z;
+    return found ? 1 : 0;
+}
+/* MakeMTLMaterial as plain numbers: head = {type, is_emissive}; tex[16][6] = {kind, r, g, b, fval, image width} */
+void pth_mtl_material(void *h, int i, int *head, float *tex) {
+    MaterialDescriptor d = MakeMTLMaterial(((MtlFile *)h)->mats.at(i));
+    head[0] = (int)d.type; head[1] = d.is_emissive;
+    for (int t = 0; t < 16; t++) {
+        const TextureDescriptor &x = d.textures[t];
+        float *o = tex + 6 * t;
+        o[0] = (float)x.type; o[1] = x.spec_val.x; o[2] = x.spec_val.y; o[3] = x.spec_val.z; o[4] = x.fval;
+        o[5] = (x.type == 2 && x.image) ? (float)x.image->width : 0.f;
+    }
+}
+void pth_mtl_free(void *h) {
+    MtlFile *f = (MtlFile *)h;
+    for (MTL *m : f->mats) delete m;
+    delete f;
+}
+
+/* LoadTextureImageData: *rgb points at width*height*3 floats owned by the handle */
+void *pth_image_load(const char *path, int *width, int *height, const float **rgb) {
+    ImageData *img = LoadTextureImageData(path);
+    if (!img) return nullptr;
+    *width = img->width; *height = img->height; *rgb = (const float *)img->data;
+    return img;
+}
+void pth_image_free(void *h) {
+    ImageData *img = (ImageData *)h;
+    if (img) { delete[] img->data; delete img; }
+}
+
+void *pth_particles_load(const char *path, const char *format) {
+    PParser *p = new PParser();
+    PParserInitialize(p, format);
+    if (!PParserParse(p, path)) { PParserCleanup(p); delete p; return nullptr; }
+    return p;
+}
+const float *pth_particles_get(void *h, int scalar, int index, int *count) {
+    return scalar ? (const float *)PParserGetScalarPtr((PParser *)h, index, count) : (const float *)PParserGetVectorPtr((PParser *)h, index, count);
+}
+void pth_particles_free(void *h) {
+    PParser *p = (PParser *)h;
+    PParserCleanup(p);
+    delete p;
+}
+}

@@ -58,6 +58,11 @@ struct Point2f {
     Point2f() : x(0), y(0) {}
     Point2f(Float a, Float b) : x(a), y(b) {}
 };
+struct vec2f {
+    Float x, y;
+    vec2f() : x(0), y(0) {}
+    vec2f(Float a, Float b) : x(a), y(b) {}
+};
 struct Point3i {
     int x, y, z;
     Point3i() : x(0), y(0), z(0) {}

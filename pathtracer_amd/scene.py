@@ -206,6 +206,26 @@ class FlatSceneBuilder:
         self.meshes.append(m)
         return self._prim(capi.SHAPE_MESH, [], mat, None, geom=len(self.meshes) - 1, **kw)
 
+    def parsed_mesh(self, mesh, mat, to_world=None, **kw):
+        """A sub-mesh as assets.load_obj returns it (ParsedMesh: per-corner position / normal / uv indices)."""
+        v = np.ascontiguousarray(mesh["p"], dtype=np.float32).reshape(-1, 3)
+        idx = np.ascontiguousarray(mesh["indices"], dtype=np.int32).reshape(-1)
+        if idx.size % 9 or v.shape[0] == 0:
+            raise ValueError("mesh without triangles")
+        m = capi.PtrMesh()
+        m.n_triangles, m.n_vertices = idx.size // 9, v.shape[0]
+        uv = np.ascontiguousarray(mesh.get("uv", np.zeros((0, 2))), dtype=np.float32).reshape(-1, 2)
+        if uv.shape[0]:
+            m.n_uvs = uv.shape[0]
+            m.uv = uv.ctypes.data_as(capi.fptr)
+            self._keep.append(uv)
+        m.p = v.ctypes.data_as(capi.fptr)
+        m.indices = idx.ctypes.data_as(capi.iptr)
+        m.to_world = transform(to_world)
+        self._keep += [v, idx]
+        self.meshes.append(m)
+        return self._prim(capi.SHAPE_MESH, [], mat, None, geom=len(self.meshes) - 1, **kw)
+
     def cloud(self, positions, radius, mat, **kw):
         p = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 3)
         c = capi.PtrCloud()
