@@ -141,6 +141,18 @@ def load_image(path):
         capi.host().pth_image_free(hd)
 
 
+def load_exr(path):
+    """ReadImageEXR (image_util.cpp:21-45): float32 [h, w, 3], rows top-down; None when the file cannot be read."""
+    w, h = C.c_int(), C.c_int()
+    p = capi.host().pth_exr_read(os.fspath(path).encode(), C.byref(w), C.byref(h))
+    if not p:
+        return None
+    try:
+        return _copy(C.cast(p, capi.fptr), (h.value, w.value, 3), np.float32)
+    finally:
+        capi.host().pth_exr_free(p)
+
+
 def load_particles(path, fmt="vs"):
     """PParserInitialize + PParserParse: ([vectors [n,3]...], [scalars [n]...]) in format order; None when the file
     is missing, has no header or its record count differs from the header."""

@@ -146,6 +146,10 @@ HOST_SIGNATURES = {
     "pth_mtl_free": (None, [C.c_void_p]),
     "pth_image_load": (C.c_void_p, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(fptr)]),
     "pth_image_free": (None, [C.c_void_p]),
+    "pth_exr_read": (C.c_void_p, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "pth_exr_free": (None, [C.c_void_p]),
+    "pth_make_sky": (None, [C.c_int, C.c_int, C.c_void_p]),
+    "pth_scene_sky_exr": (None, [C.c_char_p]),
     "pth_particles_load": (C.c_void_p, [C.c_char_p, C.c_char_p]),
     "pth_particles_get": (fptr, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "pth_particles_free": (None, [C.c_void_p]),

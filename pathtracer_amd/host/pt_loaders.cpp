@@ -617,10 +617,206 @@ bool decode_pnm(const std::vector<unsigned char> &f, std::vector<unsigned char> 
 }
 } // namespace
 
+/* ---- OpenEXR, the subset environment maps come in ---------------------------------------------------------
+ * Single-part scan-line files; compression NONE, RLE, ZIPS, ZIP; HALF, FLOAT or UINT channels; channels R, G,
+ * B (or one luminance channel, replicated) anywhere in the channel list.  Replaces tinyexr's LoadEXR as the
+ * reference uses it (image_util.cpp:21-45): rows top-down in data-window order, Spectrum(R, G, B) per pixel
+ * (the reference's Flip(Spectrum(out[it++], out[it++], out[it++])) is R, G, B under g++'s right-to-left
+ * evaluation), alpha dropped.  PIZ / PXR24 / B44 / DWA, tiles, deep data and multi-part files are reported. */
+namespace {
+float half_to_float(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t exp = (h >> 10) & 0x1fu, man = h & 0x3ffu, bits;
+    if (exp == 0) {
+        if (man == 0) bits = sign;
+        else { /* subnormal half: normalise */
+            int e = -1;
+            do { man <<= 1; e++; } while (!(man & 0x400u));
+            bits = sign | ((uint32_t)(127 - 15 - e) << 23) | ((man & 0x3ffu) << 13);
+        }
+    } else if (exp == 31) bits = sign | 0x7f800000u | (man << 13);
+    else bits = sign | ((exp + 127 - 15) << 23) | (man << 13);
+    float f;
+    memcpy(&f, &bits, 4);
+    return f;
+}
+struct ExrChannel { std::string name; int type; int xs, ys; };
+int32_t rd_i32(const unsigned char *p) { int32_t v; memcpy(&v, p, 4); return v; } /* files are little-endian, so is the host */
+uint64_t rd_u64(const unsigned char *p) { uint64_t v; memcpy(&v, p, 8); return v; }
+
+bool exr_unrle(const unsigned char *in, size_t n_in, std::vector<unsigned char> &out, size_t want) {
+    out.clear();
+    size_t i = 0;
+    while (i < n_in) {
+        int c = (signed char)in[i++];
+        if (c < 0) {
+            size_t n = (size_t)(-c);
+            if (i + n > n_in) return false;
+            out.insert(out.end(), in + i, in + i + n);
+            i += n;
+        } else {
+            if (i >= n_in) return false;
+            out.insert(out.end(), (size_t)c + 1, in[i++]);
+        }
+        if (out.size() > want) return false;
+    }
+    return out.size() == want;
+}
+/* the byte predictor and the even / odd split that ZIP and RLE blocks are stored with */
+void exr_unfilter(std::vector<unsigned char> &t, std::vector<unsigned char> &out) {
+    for (size_t i = 1; i < t.size(); i++) t[i] = (unsigned char)(t[i - 1] + t[i] - 128);
+    out.resize(t.size());
+    const size_t half = (t.size() + 1) / 2;
+    for (size_t i = 0, a = 0, b = half; i < t.size(); ) {
+        out[i++] = t[a++];
+        if (i < t.size()) out[i++] = t[b++];
+    }
+}
+bool exr_fail(const char *path, const char *why) {
+    printf("Fail read %s: %s\n", path, why);
+    return false;
+}
+bool exr_decode(const char *path, const std::vector<unsigned char> &f, std::vector<float> &rgb, int &w, int &h) {
+    if (f.size() < 16 || f[0] != 0x76 || f[1] != 0x2f || f[2] != 0x31 || f[3] != 0x01) return exr_fail(path, "not an OpenEXR file");
+    const uint32_t version = (uint32_t)rd_i32(&f[4]);
+    if ((version & 0xff) != 2) return exr_fail(path, "unknown OpenEXR version");
+    if (version & 0x1a00) return exr_fail(path, "tiled, deep or multi-part files are not supported");
+    size_t at = 8;
+    std::vector<ExrChannel> chans;
+    int compression = -1, line_order = 0, box[4] = {0, 0, -1, -1};
+    auto cstr = [&](std::string *out) {
+        size_t e = at;
+        while (e < f.size() && f[e]) e++;
+        if (e >= f.size()) return false;
+        out->assign((const char *)&f[at], e - at);
+        at = e + 1;
+        return true;
+    };
+    while (true) { /* attributes: name\0 type\0 size data, ended by an empty name */
+        std::string name, type;
+        if (!cstr(&name)) return exr_fail(path, "truncated header");
+        if (name.empty()) break;
+        if (!cstr(&type) || at + 4 > f.size()) return exr_fail(path, "truncated header");
+        const int32_t size = rd_i32(&f[at]);
+        at += 4;
+        if (size < 0 || at + (size_t)size > f.size()) return exr_fail(path, "truncated header");
+        const unsigned char *d = &f[at];
+        if (name == "channels") {
+            size_t c = 0;
+            while (c < (size_t)size && d[c]) {
+                ExrChannel ch;
+                size_t e = c;
+                while (e < (size_t)size && d[e]) e++;
+                if (e + 17 > (size_t)size) return exr_fail(path, "bad channel list");
+                ch.name.assign((const char *)d + c, e - c);
+                ch.type = rd_i32(d + e + 1);
+                ch.xs = rd_i32(d + e + 9);
+                ch.ys = rd_i32(d + e + 13);
+                chans.push_back(ch);
+                c = e + 17;
+            }
+        } else if (name == "compression" && size >= 1) compression = d[0];
+        else if (name == "dataWindow" && size >= 16) { for (int k = 0; k < 4; k++) box[k] = rd_i32(d + 4 * k); }
+        else if (name == "lineOrder" && size >= 1) line_order = d[0];
+        at += (size_t)size;
+    }
+    (void)line_order; /* every block carries its y, so the order blocks come in does not matter */
+    w = box[2] - box[0] + 1;
+    h = box[3] - box[1] + 1;
+    if (w <= 0 || h <= 0 || (int64_t)w * h > (1 << 28)) return exr_fail(path, "bad data window");
+    int lines_per_block;
+    switch (compression) {
+    case 0: case 1: case 2: lines_per_block = 1; break;
+    case 3: lines_per_block = 16; break;
+    default: return exr_fail(path, "compression not supported (NONE, RLE, ZIPS and ZIP are)");
+    }
+    int ci[3] = {-1, -1, -1}, n_colour = 0;
+    size_t line_bytes = 0;
+    std::vector<size_t> ch_off(chans.size());
+    for (size_t c = 0; c < chans.size(); c++) {
+        if (chans[c].xs != 1 || chans[c].ys != 1) return exr_fail(path, "subsampled channels are not supported");
+        if (chans[c].type < 0 || chans[c].type > 2) return exr_fail(path, "unknown pixel type");
+        ch_off[c] = line_bytes;
+        line_bytes += (size_t)w * (chans[c].type == 1 ? 2 : 4);
+        if (chans[c].name == "R") ci[0] = (int)c;
+        else if (chans[c].name == "G") ci[1] = (int)c;
+        else if (chans[c].name == "B") ci[2] = (int)c;
+    }
+    for (int k = 0; k < 3; k++) n_colour += ci[k] >= 0;
+    if (n_colour == 0) { /* a luminance image: its first non-alpha channel feeds all three */
+        for (size_t c = 0; c < chans.size() && ci[0] < 0; c++)
+            if (chans[c].name != "A") ci[0] = ci[1] = ci[2] = (int)c;
+        if (ci[0] < 0) return exr_fail(path, "no colour channel");
+    }
+    const int n_blocks = (h + lines_per_block - 1) / lines_per_block;
+    if (at + 8 * (size_t)n_blocks > f.size()) return exr_fail(path, "truncated offset table");
+    rgb.assign((size_t)w * h * 3, 0.f);
+    std::vector<unsigned char> raw, tmp;
+    for (int b = 0; b < n_blocks; b++) {
+        const uint64_t off = rd_u64(&f[at + 8 * (size_t)b]);
+        if (off + 8 > f.size()) return exr_fail(path, "block offset outside the file");
+        const int y0 = rd_i32(&f[off]) - box[1];
+        const int32_t packed = rd_i32(&f[off + 4]);
+        if (y0 < 0 || y0 >= h || packed < 0 || off + 8 + (uint64_t)packed > f.size()) return exr_fail(path, "bad block");
+        const int lines = y0 + lines_per_block <= h ? lines_per_block : h - y0;
+        const size_t want = line_bytes * lines;
+        const unsigned char *src = &f[off + 8];
+        if ((size_t)packed == want || compression == 0) { /* stored as is when packing did not help */
+            if ((size_t)packed != want) return exr_fail(path, "bad block size");
+            raw.assign(src, src + want);
+        } else if (compression == 1) {
+            if (!exr_unrle(src, (size_t)packed, tmp, want)) return exr_fail(path, "bad RLE block");
+            exr_unfilter(tmp, raw);
+        } else {
+            tmp.resize(want);
+            uLongf got = (uLongf)want;
+            if (uncompress(tmp.data(), &got, src, (uLong)packed) != Z_OK || got != want) return exr_fail(path, "bad ZIP block");
+            exr_unfilter(tmp, raw);
+        }
+        for (int l = 0; l < lines; l++)
+            for (int k = 0; k < 3; k++) {
+                if (ci[k] < 0) continue; /* missing colour channel stays 0 */
+                const ExrChannel &ch = chans[ci[k]];
+                const unsigned char *p = &raw[line_bytes * l + ch_off[ci[k]]];
+                float *out = &rgb[((size_t)(y0 + l) * w) * 3 + k];
+                for (int x = 0; x < w; x++) {
+                    float v;
+                    if (ch.type == 1) { uint16_t hv; memcpy(&hv, p + 2 * x, 2); v = half_to_float(hv); }
+                    else if (ch.type == 2) memcpy(&v, p + 4 * x, 4);
+                    else { uint32_t u; memcpy(&u, p + 4 * x, 4); v = (float)u; }
+                    out[3 * (size_t)x] = v;
+                }
+            }
+    }
+    return true;
+}
+} // namespace
+
+Spectrum *ReadImageEXR(const char *path, int &width, int &height) {
+    std::vector<unsigned char> file;
+    if (!read_file(path, file)) {
+        printf("Fail read %s: cannot open\n", path);
+        return nullptr;
+    }
+    std::vector<float> rgb;
+    if (!exr_decode(path, file, rgb, width, height)) return nullptr;
+    Spectrum *out = new Spectrum[(size_t)width * height];
+    for (size_t i = 0; i < (size_t)width * height; i++) out[i] = Spectrum(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]);
+    return out;
+}
+
 /* texture.cpp:29-64: bytes / 255.f into Spectrum, missing channels stay 0, alpha dropped */
 ImageData *LoadTextureImageData(const char *path) {
     std::vector<unsigned char> file, px;
     int nx = 0, ny = 0, nn = 0;
+    const size_t plen = strlen(path);
+    if (plen >= 4 && strcmp(path + plen - 4, ".exr") == 0) { /* texture.cpp:32-34 */
+        Spectrum *data = ReadImageEXR(path, nx, ny);
+        if (!data) return nullptr;
+        ImageData *img = new ImageData();
+        img->data = data; img->width = nx; img->height = ny; img->is_valid = 1;
+        return img;
+    }
     if (!read_file(path, file)) {
         printf("Could not open image %s\n", path);
         return nullptr;
@@ -843,6 +1039,9 @@ void *pth_image_load(const char *path, int *width, int *height, const float **rg
     *width = img->width; *height = img->height; *rgb = (const float *)img->data;
     return img;
 }
+/* ReadImageEXR: width*height*3 floats the caller releases with pth_exr_free */
+const float *pth_exr_read(const char *path, int *width, int *height) { return (const float *)ReadImageEXR(path, *width, *height); }
+void pth_exr_free(const float *p) { delete[] (Spectrum *)p; }
 void pth_image_free(void *h) {
     ImageData *img = (ImageData *)h;
     if (img) { delete[] img->data; delete img; }

@@ -40,9 +40,11 @@ bool MTLParseAll(std::vector<MTL *> *materials, std::vector<MeshMtl> *desc, cons
 MaterialDescriptor MakeMTLMaterial(MTL *mtl);
 
 /* texture.h:92.  Decoders present: PNG (8-bit, non-interlaced) and binary PPM/PGM; the reference
- * goes through stb_image, whose JPEG/BMP/TGA/... paths are not rebuilt.  nullptr when the file cannot
+ * goes through stb_image, whose JPEG/BMP/TGA/... paths are not rebuilt; ".exr" goes to ReadImageEXR.  nullptr when the file cannot
  * be decoded (the reference asserts). */
 ImageData *LoadTextureImageData(const char *path);
+/* image_util.h: RGB of an OpenEXR file, rows top-down (scan-line files, NONE / RLE / ZIPS / ZIP); nullptr on failure */
+Spectrum *ReadImageEXR(const char *path, int &width, int &height);
 
 /* part_loader.h */
 typedef struct {

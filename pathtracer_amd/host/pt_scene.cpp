@@ -514,10 +514,20 @@ void InsertLightMap(const Spectrum *pixels, int width, int height, const Transfo
     Distribution1D(lm.funcInt.data(), H, lm.margCdf.data(), &lm.margInt);
     lm.valid = true;
 }
-void InsertEXRLightMap(const char *path, const Transform &, const Spectrum &) {
-    fprintf(stderr, "[pathtracer_amd] InsertEXRLightMap(%s): the EXR reader is not part of the hot path build yet; "
-                    "decode the image yourself and call InsertLightMap\n", path);
-    exit(1);
+/* scene.cpp:703-719 + texture.cpp:217-257: read, scale, MipMap, Distribution2D */
+Spectrum *ReadImageEXR(const char *path, int &width, int &height); /* pt_loaders.cpp */
+void InsertEXRLightMap(const char *path, const Transform &toWorld, const Spectrum &scale) {
+    if (g_lightMap.valid) { printf("Warning: Multiple calls to InsertLightMap\n"); return; }
+    printf("Generating environment map\n * Reading EXR Map...");
+    int width = 0, height = 0;
+    Spectrum *L = ReadImageEXR(path, width, height);
+    if (!L) { /* the reference asserts on a null image */
+        fprintf(stderr, "[pathtracer_amd] InsertEXRLightMap(%s): could not read the image\n", path);
+        exit(1);
+    }
+    printf("OK\n");
+    InsertLightMap(L, width, height, toWorld, scale);
+    delete[] L;
 }
 
 /* ---- flattening -------------------------------------------------------------------------------------- */

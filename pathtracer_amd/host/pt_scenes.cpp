@@ -25,6 +25,8 @@ struct Pcg { /* PCG32 for synthetic data only (never on the render path) */
     float uniform() { return (next() >> 8) * (1.0f / 16777216.0f); }
 };
 
+static std::string g_sky_exr; /* when set (pth_scene_sky_exr), ZooScene reads its sky from this file */
+
 /* analytic sky + sun, equirectangular, stands in for skylight-sunset.exr (main.cpp:479) */
 std::vector<Spectrum> MakeSky(int w, int h) {
     std::vector<Spectrum> px((size_t)w * h);
@@ -169,7 +171,8 @@ void ZooScene(Camera *camera, Float aspect, int variant) {
     if (variant & 1) {
         static std::vector<Spectrum> sky;
         if (sky.empty()) sky = MakeSky(256, 128);
-        InsertLightMap(sky.data(), 256, 128, RotateX(-90) * RotateZ(90), Spectrum(1.0));
+        if (!g_sky_exr.empty()) InsertEXRLightMap(g_sky_exr.c_str(), RotateX(-90) * RotateZ(90), Spectrum(1.0)); /* the file route */
+        else InsertLightMap(sky.data(), 256, 128, RotateX(-90) * RotateZ(90), Spectrum(1.0));
     }
     if (variant & 2) InsertCameraMedium(MakeMedium(Spectrum(.004), Spectrum(.012), 0.3));
 }
@@ -337,6 +340,13 @@ void pth_scene_free(void *h) {
     FlatSceneFree(b->flat);
     delete b;
 }
+
+/* the sky the scene functions generate, and a switch that makes ZooScene load its sky from an .exr instead */
+void pth_make_sky(int w, int h, float *rgb) {
+    std::vector<Spectrum> s = MakeSky(w, h);
+    memcpy(rgb, s.data(), s.size() * sizeof(Spectrum));
+}
+void pth_scene_sky_exr(const char *path) { g_sky_exr = path ? path : ""; }
 
 /* transform factories exposed for the boundary unit tests */
 void pth_transform(const char *kind, float a, float b, float c, float d, PtrTransform *out) {

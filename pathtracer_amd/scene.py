@@ -7,6 +7,7 @@ Two sources of a ``PtrFlatScene``:
 * :class:`FlatSceneBuilder` - small scenes assembled directly from numpy arrays (tests, tools).
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -16,9 +17,13 @@ from . import capi
 class BuiltScene:
     """name: cornell | knot | zoo | volcaustic | fluid | subsurface; p0 = size, p1 = variant."""
 
-    def __init__(self, name, width, height, p0=0, p1=0):
+    def __init__(self, name, width, height, p0=0, p1=0, sky_exr=None):
         h = capi.host()
-        self._h = h.pth_scene_build(name.encode(), int(width), int(height), int(p0), int(p1))
+        h.pth_scene_sky_exr(os.fspath(sky_exr).encode() if sky_exr else None)  # zoo: the sky comes from this .exr (InsertEXRLightMap)
+        try:
+            self._h = h.pth_scene_build(name.encode(), int(width), int(height), int(p0), int(p1))
+        finally:
+            h.pth_scene_sky_exr(None)
         if not self._h:
             raise ValueError("unknown scene family %r" % name)
         self.name, self.width, self.height = name, int(width), int(height)
