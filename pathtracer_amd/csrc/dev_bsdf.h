@@ -29,13 +29,43 @@ struct Lobe { /* 16 words; a field is written only by the lobe kinds that read i
     int fr_type;
     float fr_etaI, fr_etaT;
 };
+/* The lobes of a BSDF live in LDS, not in the struct: a lobe array indexed at run time would sit in scratch
+ * memory, and the ~300 lobe words a vertex reads back (every lobe, for f, pdf and the sample) then come from
+ * L2 / Infinity Cache (8 waves x 64 lanes x 320 B per CU is far beyond the L1).  The kernel lends each lane a
+ * column of a __shared__ array: word w of lobe i is lm[(i * 16 + w) * LOBE_STRIDE] (LOBE_STRIDE = threads per
+ * block, so a wavefront's accesses are conflict-free).  Lobes are read into registers to be evaluated. */
+#define LOBE_WORDS 16
+#define LOBE_STRIDE 256 /* = TPB of the kernels that shade (rt_common.h) */
+#define LOBE_LDS_WORDS (MAX_LOBES * LOBE_WORDS * LOBE_STRIDE)
 struct BSDF {
-    Lobe l[MAX_LOBES];
+    float *lm; /* this lane's lobe column (set by the kernel before bsdf_init) */
     int n;
     f3 ns, ss, ts; /* ng == ns (reflection.h:367-372) */
 };
+PD int lobe_type(const BSDF &b, int i) { return __float_as_int(b.lm[(i * LOBE_WORDS) * LOBE_STRIDE]); }
+PD Lobe lobe_load(const BSDF &b, int i) {
+    const float *p = b.lm + (i * LOBE_WORDS) * LOBE_STRIDE;
+    Lobe l;
+    l.type = __float_as_int(p[0]); l.impl = __float_as_int(p[1 * LOBE_STRIDE]);
+    l.S = f3(p[2 * LOBE_STRIDE], p[3 * LOBE_STRIDE], p[4 * LOBE_STRIDE]);
+    l.T = f3(p[5 * LOBE_STRIDE], p[6 * LOBE_STRIDE], p[7 * LOBE_STRIDE]);
+    l.A = p[8 * LOBE_STRIDE]; l.B = p[9 * LOBE_STRIDE]; l.C = p[10 * LOBE_STRIDE];
+    l.ax = p[11 * LOBE_STRIDE]; l.ay = p[12 * LOBE_STRIDE];
+    l.fr_type = __float_as_int(p[13 * LOBE_STRIDE]); l.fr_etaI = p[14 * LOBE_STRIDE]; l.fr_etaT = p[15 * LOBE_STRIDE];
+    return l;
+}
+PD void lobe_push(BSDF *b, const Lobe &l) {
+    float *p = b->lm + (b->n * LOBE_WORDS) * LOBE_STRIDE;
+    b->n += 1;
+    p[0] = __int_as_float(l.type); p[1 * LOBE_STRIDE] = __int_as_float(l.impl);
+    p[2 * LOBE_STRIDE] = l.S.x; p[3 * LOBE_STRIDE] = l.S.y; p[4 * LOBE_STRIDE] = l.S.z;
+    p[5 * LOBE_STRIDE] = l.T.x; p[6 * LOBE_STRIDE] = l.T.y; p[7 * LOBE_STRIDE] = l.T.z;
+    p[8 * LOBE_STRIDE] = l.A; p[9 * LOBE_STRIDE] = l.B; p[10 * LOBE_STRIDE] = l.C;
+    p[11 * LOBE_STRIDE] = l.ax; p[12 * LOBE_STRIDE] = l.ay;
+    p[13 * LOBE_STRIDE] = __int_as_float(l.fr_type); p[14 * LOBE_STRIDE] = l.fr_etaI; p[15 * LOBE_STRIDE] = l.fr_etaT;
+}
 
-PD bool lobe_matches(const Lobe &b, int t) { return (b.type & t) == b.type; }
+PD bool type_matches(int type, int t) { return (type & t) == type; }
 
 /* ---- Fresnel, material.cpp:5-73 ---- */
 PD float fr_dielectric(float cosThetaI, float etaI, float etaT) {
@@ -158,7 +188,8 @@ PD f3 bssrdf_sw(float eta, const f3 &w) {
     return f3((float)((1 - fr_dielectric(cos_theta(w), 1, eta)) / (c * kPi)));
 }
 
-LOBE_FN float lobe_pdf(const Lobe &b, const f3 &wo, const f3 &wi) {
+LOBE_FN float lobe_pdf_v(Lobe b, float wox, float woy, float woz, float wix, float wiy, float wiz) {
+    const f3 wo(wox, woy, woz), wi(wix, wiy, wiz);
     switch (b.impl) {
     case LB_LAMBERT_R: case LB_OREN_NAYAR: case LB_BSSRDF_ADAPTER: return same_hemisphere(wo, wi) ? abs_cos_theta(wi) * kInvPi : 0;
     case LB_LAMBERT_T: return !same_hemisphere(wo, wi) ? abs_cos_theta(wi) * kInvPi : 0;
@@ -186,7 +217,9 @@ LOBE_FN float lobe_pdf(const Lobe &b, const f3 &wo, const f3 &wi) {
     default: return 0;
     }
 }
-LOBE_FN f3 lobe_f(const Lobe &b, const f3 &wo, const f3 &wi) {
+PD float lobe_pdf(const Lobe &b, const f3 &wo, const f3 &wi) { return lobe_pdf_v(b, wo.x, wo.y, wo.z, wi.x, wi.y, wi.z); }
+LOBE_FN f3 lobe_f_v(Lobe b, float wox, float woy, float woz, float wix, float wiy, float wiz) {
+    const f3 wo(wox, woy, woz), wi(wix, wiy, wiz);
     switch (b.impl) {
     case LB_LAMBERT_R: case LB_LAMBERT_T: return b.S * (float)kInvPi;
     case LB_OREN_NAYAR: {
@@ -244,7 +277,22 @@ LOBE_FN f3 lobe_f(const Lobe &b, const f3 &wo, const f3 &wi) {
     default: return f3(0.f);
     }
 }
-LOBE_FN f3 lobe_sample_f(const Lobe &b, const f3 &wo, f3 *wi, const f2 &u, float *pdf, int *sampledType) {
+PD f3 lobe_f(const Lobe &b, const f3 &wo, const f3 &wi) { return lobe_f_v(b, wo.x, wo.y, wo.z, wi.x, wi.y, wi.z); }
+/* by value in and out: everything travels in registers (a pointer argument would pin the caller's variable to scratch) */
+struct LobeSample { f3 f, wi; float pdf; int type; };
+PD f3 lobe_sample_f_body(const Lobe &b, const f3 &wo, f3 *wi, const f2 &u, float *pdf, int *sampledType);
+LOBE_FN LobeSample lobe_sample_f_v(Lobe b, float wox, float woy, float woz, float ux, float uy, int type_in) {
+    LobeSample r;
+    r.wi = f3(0.f); r.pdf = 0; r.type = type_in;
+    r.f = lobe_sample_f_body(b, f3(wox, woy, woz), &r.wi, f2(ux, uy), &r.pdf, &r.type);
+    return r;
+}
+PD f3 lobe_sample_f(const Lobe &b, const f3 &wo, f3 *wi, const f2 &u, float *pdf, int *sampledType) {
+    const LobeSample r = lobe_sample_f_v(b, wo.x, wo.y, wo.z, u.x, u.y, *sampledType);
+    *wi = r.wi; *pdf = r.pdf; *sampledType = r.type;
+    return r.f;
+}
+PD f3 lobe_sample_f_body(const Lobe &b, const f3 &wo, f3 *wi, const f2 &u, float *pdf, int *sampledType) {
     switch (b.impl) {
     case LB_LAMBERT_R: case LB_OREN_NAYAR: case LB_BSSRDF_ADAPTER:
         *wi = cosine_sample_hemisphere(u);
@@ -339,7 +387,7 @@ PD f3 bsdf_to_world(const BSDF &b, const f3 &v) {
 }
 PD int bsdf_num_components(const BSDF &b, int flags) {
     int num = 0;
-    for (int i = 0; i < b.n; ++i) if (lobe_matches(b.l[i], flags)) ++num;
+    for (int i = 0; i < b.n; ++i) if (type_matches(lobe_type(b, i), flags)) ++num;
     return num;
 }
 PD f3 bsdf_f(const BSDF &b, const f3 &woW, const f3 &wiW, int flags) {
@@ -348,9 +396,10 @@ PD f3 bsdf_f(const BSDF &b, const f3 &woW, const f3 &wiW, int flags) {
     if (is_zero(wo.z)) return f3(0.f);
     bool refl = dot(wiW, b.ns) * dot(woW, b.ns) > 0;
     f3 f(0.f);
-    for (int i = 0; i < b.n; ++i)
-        if (lobe_matches(b.l[i], flags) && ((refl && (b.l[i].type & BSDF_REFLECTION)) || (!refl && (b.l[i].type & BSDF_TRANSMISSION))))
-            f += lobe_f(b.l[i], wo, wi);
+    for (int i = 0; i < b.n; ++i) {
+        const int ty = lobe_type(b, i);
+        if (type_matches(ty, flags) && ((refl && (ty & BSDF_REFLECTION)) || (!refl && (ty & BSDF_TRANSMISSION)))) f += lobe_f(lobe_load(b, i), wo, wi);
+    }
     return f;
 }
 PD float bsdf_pdf(const BSDF &b, const f3 &woW, const f3 &wiW, int flags) {
@@ -360,7 +409,7 @@ PD float bsdf_pdf(const BSDF &b, const f3 &woW, const f3 &wiW, int flags) {
     float pdf = 0.f;
     int matching = 0;
     for (int i = 0; i < b.n; i++)
-        if (lobe_matches(b.l[i], flags)) { pdf += lobe_pdf(b.l[i], wo, wi); matching += 1; }
+        if (type_matches(lobe_type(b, i), flags)) { pdf += lobe_pdf(lobe_load(b, i), wo, wi); matching += 1; }
     return matching > 0 ? pdf / matching : 0.f;
 }
 PD f3 bsdf_sample_f(const BSDF &b, const f3 &woW, f3 *wiW, const f2 &u, float *pdf, int type, int *sampledType) {
@@ -369,26 +418,27 @@ PD f3 bsdf_sample_f(const BSDF &b, const f3 &woW, f3 *wiW, const f2 &u, float *p
     int comp_i = (int)fminr((float)(int)floorf(u.x * matching), (float)(matching - 1));
     int count = comp_i, picked = -1;
     for (int i = 0; i < b.n; ++i)
-        if (lobe_matches(b.l[i], type) && count-- == 0) { picked = i; break; }
+        if (type_matches(lobe_type(b, i), type) && count-- == 0) { picked = i; break; }
     f2 uR(fminr(u.x * matching - comp_i, kOneMinusEpsilon), u.y);
     f3 wi, wo = bsdf_to_local(b, woW);
     if (is_zero(wo.z)) return f3(0.f);
     *pdf = 0;
-    int ptype = b.l[picked].type;
+    int ptype = lobe_type(b, picked);
     *sampledType = ptype;
-    f3 f = lobe_sample_f(b.l[picked], wo, &wi, uR, pdf, sampledType);
+    f3 f = lobe_sample_f(lobe_load(b, picked), wo, &wi, uR, pdf, sampledType);
     if (is_zero(*pdf)) { *sampledType = 0; return f3(0.f); }
     *wiW = bsdf_to_world(b, wi);
     if (!(ptype & BSDF_SPECULAR) && matching > 1)
         for (int i = 0; i < b.n; ++i)
-            if (i != picked && lobe_matches(b.l[i], type)) *pdf += lobe_pdf(b.l[i], wo, wi);
+            if (i != picked && type_matches(lobe_type(b, i), type)) *pdf += lobe_pdf(lobe_load(b, i), wo, wi);
     if (matching > 1) *pdf /= matching;
     if (!(ptype & BSDF_SPECULAR)) {
         bool refl = dot(*wiW, b.ns) * dot(woW, b.ns) > 0;
         f = f3(0.f);
-        for (int i = 0; i < b.n; ++i)
-            if (lobe_matches(b.l[i], type) && ((refl && (b.l[i].type & BSDF_REFLECTION)) || (!refl && (b.l[i].type & BSDF_TRANSMISSION))))
-                f += lobe_f(b.l[i], wo, wi);
+        for (int i = 0; i < b.n; ++i) {
+            const int ty = lobe_type(b, i);
+            if (type_matches(ty, type) && ((refl && (ty & BSDF_REFLECTION)) || (!refl && (ty & BSDF_TRANSMISSION)))) f += lobe_f(lobe_load(b, i), wo, wi);
+        }
     }
     return f;
 }
@@ -419,40 +469,47 @@ PD float tex_float(const DScene &sc, const DTex &t, const f2 &uv) {
 }
 
 /* ---- lobe constructors, reflection.h:131-246 ---- */
-PD void lobe_clear(Lobe &b) {
-    b.type = 0; b.impl = LB_INVALID; b.fr_type = FR_NOOP; /* the rest is set by the constructor of the kind that reads it */
+PD void lobe_clear(Lobe &b) { /* fields a lobe kind does not set are never read by it */
+    b.type = 0; b.impl = LB_INVALID; b.fr_type = FR_NOOP;
+    b.S = f3(0.f); b.T = f3(0.f); b.A = b.B = b.C = 0; b.ax = b.ay = 0; b.fr_etaI = b.fr_etaT = 0;
 }
-PD void push_lambert_r(BSDF *b, const f3 &R) { Lobe &l = b->l[b->n++]; lobe_clear(l); l.type = BSDF_REFLECTION | BSDF_DIFFUSE; l.impl = LB_LAMBERT_R; l.S = R; }
-PD void push_lambert_t(BSDF *b, const f3 &T) { Lobe &l = b->l[b->n++]; lobe_clear(l); l.type = BSDF_TRANSMISSION | BSDF_DIFFUSE; l.impl = LB_LAMBERT_T; l.S = T; }
+PD void push_lambert_r(BSDF *b, const f3 &R) { Lobe l; lobe_clear(l); l.type = BSDF_REFLECTION | BSDF_DIFFUSE; l.impl = LB_LAMBERT_R; l.S = R; lobe_push(b, l); }
+PD void push_lambert_t(BSDF *b, const f3 &T) { Lobe l; lobe_clear(l); l.type = BSDF_TRANSMISSION | BSDF_DIFFUSE; l.impl = LB_LAMBERT_T; l.S = T; lobe_push(b, l); }
 PD void push_oren_nayar(BSDF *b, const f3 &R, float sigma) {
-    Lobe &l = b->l[b->n++]; lobe_clear(l); l.type = BSDF_REFLECTION | BSDF_DIFFUSE; l.impl = LB_OREN_NAYAR; l.S = R;
+    Lobe l; lobe_clear(l); l.type = BSDF_REFLECTION | BSDF_DIFFUSE; l.impl = LB_OREN_NAYAR; l.S = R;
     float sigma2 = sigma * sigma;
     l.A = 1.f - (sigma2 / (2.f * (sigma2 + 0.33f)));
     l.B = 0.45f * sigma2 / (sigma2 + 0.09f);
+    lobe_push(b, l);
 }
 PD void push_spec_r(BSDF *b, const f3 &R, int frt, float eI, float eT) {
-    Lobe &l = b->l[b->n++]; lobe_clear(l); l.type = BSDF_REFLECTION | BSDF_SPECULAR; l.impl = LB_SPEC_R; l.S = R;
+    Lobe l; lobe_clear(l); l.type = BSDF_REFLECTION | BSDF_SPECULAR; l.impl = LB_SPEC_R; l.S = R;
     l.fr_type = frt; l.fr_etaI = eI; l.fr_etaT = eT;
+    lobe_push(b, l);
 }
 PD void push_spec_t(BSDF *b, const f3 &T, float eA, float eB) {
-    Lobe &l = b->l[b->n++]; lobe_clear(l); l.type = BSDF_TRANSMISSION | BSDF_SPECULAR; l.impl = LB_SPEC_T; l.S = T; l.A = eA; l.B = eB;
+    Lobe l; lobe_clear(l); l.type = BSDF_TRANSMISSION | BSDF_SPECULAR; l.impl = LB_SPEC_T; l.S = T; l.A = eA; l.B = eB;
     l.fr_type = FR_DIELECTRIC; l.fr_etaI = eA; l.fr_etaT = eB;
+    lobe_push(b, l);
 }
 PD void push_fresnel_spec(BSDF *b, const f3 &R, const f3 &T, float eA, float eB) {
-    Lobe &l = b->l[b->n++]; lobe_clear(l); l.type = BSDF_REFLECTION | BSDF_TRANSMISSION | BSDF_SPECULAR; l.impl = LB_FRESNEL_SPEC;
+    Lobe l; lobe_clear(l); l.type = BSDF_REFLECTION | BSDF_TRANSMISSION | BSDF_SPECULAR; l.impl = LB_FRESNEL_SPEC;
     l.S = R; l.T = T; l.A = eA; l.B = eB;
+    lobe_push(b, l);
 }
 PD void push_micro_t(BSDF *b, const f3 &T, float eA, float eB, float ax, float ay, bool remap) {
-    Lobe &l = b->l[b->n++]; lobe_clear(l); l.type = BSDF_TRANSMISSION | BSDF_GLOSSY; l.impl = LB_MICRO_T; l.A = eA; l.B = eB; l.T = T;
+    Lobe l; lobe_clear(l); l.type = BSDF_TRANSMISSION | BSDF_GLOSSY; l.impl = LB_MICRO_T; l.A = eA; l.B = eB; l.T = T;
     l.fr_type = FR_DIELECTRIC; l.fr_etaI = eA; l.fr_etaT = eB;
     l.ax = remap ? roughness_to_alpha(ax) : ax;
     l.ay = remap ? roughness_to_alpha(ay) : ay;
+    lobe_push(b, l);
 }
 PD void push_micro_r_diel(BSDF *b, const f3 &R, float ax, float ay, float eI, float eT, bool remap) {
-    Lobe &l = b->l[b->n++]; lobe_clear(l); l.type = BSDF_REFLECTION | BSDF_GLOSSY; l.impl = LB_MICRO_R; l.S = R;
+    Lobe l; lobe_clear(l); l.type = BSDF_REFLECTION | BSDF_GLOSSY; l.impl = LB_MICRO_R; l.S = R;
     l.fr_type = FR_DIELECTRIC; l.fr_etaI = eI; l.fr_etaT = eT;
     l.ax = remap ? roughness_to_alpha(ax) : ax;
     l.ay = remap ? roughness_to_alpha(ay) : ay;
+    lobe_push(b, l);
 }
 /* glass.cpp:26-57 and the glossy halves of subsurface.cpp:35-67 / kdsubsurface.cpp:126-158 */
 PD void glass_lobes(BSDF *b, const f3 &R, const f3 &T, float eta, float ur, float vr, bool subsurfaceOrder) {
@@ -511,12 +568,13 @@ PD bool compute_scattering(const DScene &sc, const SI &si, BSDF *bsdf, BssrdfPar
     } break;
     case MT_METAL: {
         float ur = tex_float(sc, tx[2], uv), vr = tex_float(sc, tx[3], uv);
-        Lobe &l = bsdf->l[bsdf->n++];
+        Lobe l;
         lobe_clear(l);
         l.type = BSDF_REFLECTION | BSDF_GLOSSY; l.impl = LB_MICRO_R; l.S = f3(1.f);
         l.fr_type = FR_CONDUCTOR; l.T = tex_spec(sc, tx[0], uv);
         { f3 k = tex_spec(sc, tx[1], uv); l.A = k.x; l.B = k.y; l.C = k.z; }
         l.ax = roughness_to_alpha(ur); l.ay = roughness_to_alpha(vr);
+        lobe_push(bsdf, l);
     } break;
     case MT_PLASTIC: {
         f3 kd = tex_spec(sc, tx[0], uv);

@@ -336,11 +336,12 @@ PD bool bssrdf_step(const DScene &sc, BSDF &bsdf, const BssrdfParams &bp, const 
     f2 u2 = rand2(rng);
     f3 S = bssrdf_sample_sp(sc, b, u1, u2, &pi, &pdf, probes, ls);
     if (!is_black(S)) { /* Sample_S, bssrdf.cpp:447-460: the exit vertex scatters through the Sw adapter lobe */
-        Lobe &lb = bsdf.l[bsdf.n++];
+        Lobe lb;
         lobe_clear(lb);
         lb.type = BSDF_REFLECTION | BSDF_DIFFUSE;
         lb.impl = LB_BSSRDF_ADAPTER;
         lb.C = b.eta;
+        lobe_push(&bsdf, lb);
         pi.wo = pi.n;
     }
     if (is_black(S) || is_zero(pdf)) return false;

@@ -34,7 +34,7 @@ struct SssCtx {
  * On entry (ro, rd) is the ray that was traced and (hp, hf, ht) its closest hit (hp < 0: miss). */
 template <bool SSS, class NeeSink>
 PD VertexOut shade_vertex(const DScene &sc, int integrator, Rng &rng, f3 &ro, f3 &rd, int &ray_medium, int hp, int hf, float ht, f3 &L,
-                          f3 &beta, int &bounces, int &pflags, const NeeSink &rec, VertexCtr &ctr, const SssCtx *sss = nullptr) {
+                          f3 &beta, int &bounces, int &pflags, const NeeSink &rec, VertexCtr &ctr, const SssCtx *sss, float *lobe_mem) {
     VertexOut out;
     out.alive = false;
     out.want_nee = false;
@@ -44,6 +44,8 @@ PD VertexOut shade_vertex(const DScene &sc, int integrator, Rng &rng, f3 &ro, f3
     const bool found = hp >= 0;
     SI si;
     BSDF bsdf;
+    bsdf.lm = lobe_mem; /* this lane's column of the kernel's lobe array (dev_bsdf.h) */
+    bsdf.n = 0;
     BssrdfParams bp;
 
     if (integrator == PTR_LI_DIRECT) { /* main.cpp:72-98 */

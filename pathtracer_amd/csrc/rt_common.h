@@ -11,6 +11,7 @@
 #include <cstddef>
 
 #define TPB 256
+static_assert(TPB == LOBE_STRIDE, "the lobe columns in LDS are strided by the block size (dev_bsdf.h)");
 #ifndef PT_WAVES
 #define PT_WAVES 5 /* wavefronts per SIMD the persistent tracer is compiled for */
 #endif

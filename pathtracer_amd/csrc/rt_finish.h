@@ -14,6 +14,7 @@ template <bool SSS>
 __global__ void __launch_bounds__(TPB) k_finish(DScene sc, Pipe pp, PassParams prm, const int *n_ptr, int n_host, const int *queue, int walk,
                                                 unsigned long long *ctrs) {
     __shared__ int s_stack[LDS_STACK * TRACE_TPB];
+    __shared__ float s_lobes[LOBE_LDS_WORDS];
     LaneStack ls;
     ls.lds = &s_stack[threadIdx.x];
     VertexCtr ctr;
@@ -40,7 +41,7 @@ __global__ void __launch_bounds__(TPB) k_finish(DScene sc, Pipe pp, PassParams p
             float tmax = kInfinity, b0 = 0, b1 = 0;
             int hp = -1, hf = -1;
             bool hit = traverse<false, false>(sc, ro, rd, tmax, hp, hf, b0, b1, nullptr, ls);
-            VertexOut vo = shade_vertex<SSS>(sc, prm.integrator, rng, ro, rd, med, hit ? hp : -1, hit ? hf : -1, tmax, L, beta, bounces, pflags, NeeToStruct{rec}, ctr, &sss);
+            VertexOut vo = shade_vertex<SSS>(sc, prm.integrator, rng, ro, rd, med, hit ? hp : -1, hit ? hf : -1, tmax, L, beta, bounces, pflags, NeeToStruct{rec}, ctr, &sss, &s_lobes[threadIdx.x]);
             if (vo.want_nee) {
                 f3 Ld;
                 if (walk) {

@@ -13,6 +13,7 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(SSS ? 
 k_shade(DScene sc, Pipe pp, PassParams prm, const int *n_ptr, int n_host, const int *queue, int *q_next, int *q_nee, int *q_shadow, int *q_mis,
         int *counts, int walk, unsigned long long *ctrs) {
     __shared__ int s_stack[SSS ? LDS_STACK * TRACE_TPB : 1];
+    __shared__ float s_lobes[LOBE_LDS_WORDS]; /* 80 KB: the BSDF lobes of the block's 256 vertices (dev_bsdf.h) */
     LaneStack ls;
     ls.lds = &s_stack[SSS ? threadIdx.x : 0];
     NeeCtr nctr;
@@ -39,7 +40,7 @@ k_shade(DScene sc, Pipe pp, PassParams prm, const int *n_ptr, int n_host, const 
         f3 L = ld3(ps.L), beta = ld3(ps.beta);
         int med = ps.medium, bounces = ps.bounces, pflags = ps.flags;
         VertexOut vo = shade_vertex<SSS>(sc, prm.integrator, rng, ro, rd, med, pp.hprim[slot], pp.hface[slot], pp.ht[slot], L, beta, bounces,
-                                         pflags, rec, ctr, &sss);
+                                         pflags, rec, ctr, &sss, &s_lobes[threadIdx.x]);
         alive = vo.alive;
         want_nee = vo.want_nee;
         want_shadow = want_nee && (vo.nee_flags & NEE_A);
