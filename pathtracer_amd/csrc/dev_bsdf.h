@@ -14,7 +14,9 @@ enum { LB_LAMBERT_R = 0, LB_LAMBERT_T, LB_SPEC_R, LB_SPEC_T, LB_FRESNEL_SPEC, LB
        LB_BSSRDF_ADAPTER, LB_INVALID };
 enum { FR_NOOP = 0, FR_DIELECTRIC = 1, FR_CONDUCTOR = 2 };
 enum { MT_MATTE = 1, MT_MIRROR, MT_GLASS, MT_METAL, MT_TRANSLUCENT, MT_PLASTIC, MT_UBER, MT_SUBSURFACE, MT_KDSUBSURFACE, MT_PLAYGROUND };
+#ifndef MAX_LOBES
 #define MAX_LOBES 5
+#endif
 /* The three per-lobe switches are called from a dozen places of a shade kernel; kept out of line (one
  * copy each): fewer spills around them (114 instead of 194 VGPRs), half the compile time, shade 6 % faster. */
 #define LOBE_FN static __device__ __noinline__

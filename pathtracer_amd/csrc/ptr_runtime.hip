@@ -186,6 +186,52 @@ __global__ void __launch_bounds__(TPB) k_miss(DScene sc, Pipe pp, PassParams prm
     ctr_flush(ctrs, C_MISS, miss);
 }
 
+/* The four queues a bounce leaves behind - surviving paths, direct-light records, shadow rays, MIS rays - from
+ * the route bits k_shade wrote (rt_common.h ROUTE_*).  Like k_miss, a wavefront takes ROUTE_CHUNK x 64 entries and
+ * reserves its share of each queue with one atomic per queue (lane q serves queue q). */
+#define ROUTE_CHUNK 8
+__global__ void __launch_bounds__(TPB) k_route(const int *n_ptr, const int *queue, const int *route, int *q_next, int *q_nee, int *q_shadow,
+                                               int *q_mis, int *counts) {
+    const int n = *n_ptr;
+    const int lane = __lane_id();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int wave = (blockIdx.x * TPB + threadIdx.x) >> 6, n_waves = (gridDim.x * TPB) >> 6;
+    int *const qs[4] = {q_next, q_nee, q_shadow, q_mis};
+    for (long long base = (long long)wave * 64 * ROUTE_CHUNK; base < n; base += (long long)n_waves * 64 * ROUTE_CHUNK) {
+        int slots[ROUTE_CHUNK], bits[ROUTE_CHUNK];
+#pragma unroll
+        for (int c = 0; c < ROUTE_CHUNK; c++) {
+            const long long i = base + c * 64 + lane;
+            slots[c] = 0;
+            bits[c] = 0;
+            if (i < n) {
+                slots[c] = queue[i];
+                bits[c] = route[slots[c]];
+            }
+        }
+        int mine = 0; /* lane q: entries this group adds to queue q */
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            int kept = 0;
+#pragma unroll
+            for (int c = 0; c < ROUTE_CHUNK; c++) kept += __popcll(__ballot((bits[c] >> q) & 1));
+            if (lane == q) mine = kept;
+        }
+        int at = 0;
+        if (lane < 4 && mine) at = atomicAdd(counts + lane, mine);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            int out = __shfl(at, q, 64);
+#pragma unroll
+            for (int c = 0; c < ROUTE_CHUNK; c++) {
+                const unsigned long long m = __ballot((bits[c] >> q) & 1);
+                if ((bits[c] >> q) & 1) qs[q][out + __popcll(m & lt)] = slots[c];
+                out += __popcll(m);
+            }
+        }
+    }
+}
+
 /* sum of a direct-light record whose two rays went through the persistent tracer */
 __global__ void __launch_bounds__(TPB) k_nee_resolve(DScene sc, Pipe pp, const int *n_ptr, int n_host, const int *queue,
                                                      unsigned long long *ctrs) {
@@ -475,6 +521,8 @@ static void enqueue_shade(PtrContext *ctx, Lane &l, const PassParams &prm, const
     const ShadeArgs a = {ctx->sc, l.pipe, prm, hit_count, 0, l.queues[5], q_next, l.queues[2], l.queues[3], l.queues[4], cnt, walk_i, ctx->ctrs};
     if (ctx->scene_has_sss) rt_launch_shade_sss(stride_blocks, s, a);
     else rt_launch_shade(stride_blocks, s, a);
+    hipLaunchKernelGGL(k_route, dim3(clampu(nblocks((n_upper + ROUTE_CHUNK - 1) / ROUTE_CHUNK), 32, 2048)), dim3(TPB), 0, s, (const int *)hit_count,
+                       (const int *)l.queues[5], (const int *)l.pipe.hprim, q_next, l.queues[2], l.queues[3], l.queues[4], cnt);
 }
 /* direct light of the bounce when a shadow / MIS ray may pass through primitives (Li_VolPath with
  * medium boundaries or emitters): the walks of VisibilityTester::Tr / IntersectTr run in-kernel */

@@ -86,6 +86,9 @@ __device__ __forceinline__ void queue_append(int *counter, int *queue, bool pred
     }
 }
 
+/* bits k_shade leaves in hprim[slot] for k_route (ptr_runtime.hip); bit q feeds queue q = counts[q] */
+enum { ROUTE_NEXT = 1, ROUTE_NEE = 2, ROUTE_SHADOW = 4, ROUTE_MIS = 8 };
+
 enum { C_TOTAL = 0, C_MISS, C_SURF, C_MED, C_LIGHT, C_ZERO, C_SHADOW, C_MIS, C_PROBE, C_CAMERA, C_NODES, C_PRIMS, C_COUNT };
 
 /* grid-stride helper: every lane of a wavefront runs the same number of rounds, so the ballots of

@@ -63,10 +63,9 @@ k_shade(DScene sc, Pipe pp, PassParams prm, const int *n_ptr, int n_host, const 
             pp.rd[slot] = rd.x; pp.rd[cap + slot] = rd.y; pp.rd[2 * cap + slot] = rd.z;
         }
     }
-    queue_append(&counts[0], q_next, alive, slot);
-    queue_append(&counts[1], q_nee, want_nee, slot);
-    queue_append(&counts[2], q_shadow, want_shadow, slot);
-    queue_append(&counts[3], q_mis, want_mis, slot);
+    /* where the vertex goes next is left in its (consumed) hit word; k_route turns these into the four queues.
+     * Appending here cost one atomic per wavefront and queue on a single cache line: a third of the kernel. */
+    if (i < n) pp.hprim[slot] = (alive ? ROUTE_NEXT : 0) | (want_nee ? ROUTE_NEE : 0) | (want_shadow ? ROUTE_SHADOW : 0) | (want_mis ? ROUTE_MIS : 0);
     GRID_STRIDE_END
     ctr_flush(ctrs, C_TOTAL, ctr.total);
     ctr_flush(ctrs, C_MISS, ctr.miss);
