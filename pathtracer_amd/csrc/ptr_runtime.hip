@@ -679,8 +679,8 @@ int ptr_create(int device, PtrContext **out) {
     memset(ctx->prof_ms, 0, sizeof(ctx->prof_ms));
     memset(ctx->prof_launches, 0, sizeof(ctx->prof_launches));
     memset(ctx->prof_items, 0, sizeof(ctx->prof_items));
-    bool ok = hipMalloc((void **)&ctx->ctrs, C_COUNT * sizeof(unsigned long long)) == hipSuccess &&
-              hipMemset(ctx->ctrs, 0, C_COUNT * sizeof(unsigned long long)) == hipSuccess &&
+    bool ok = hipMalloc((void **)&ctx->ctrs, CTR_REPLICAS * CTR_STRIDE * sizeof(unsigned long long)) == hipSuccess &&
+              hipMemset(ctx->ctrs, 0, CTR_REPLICAS * CTR_STRIDE * sizeof(unsigned long long)) == hipSuccess &&
               hipMalloc((void **)&ctx->api_fetch, API_FETCH_SLOTS * sizeof(int)) == hipSuccess;
     for (Lane &l : ctx->lanes) {
         memset(&l.pipe, 0, sizeof(l.pipe));
@@ -1002,7 +1002,13 @@ int ptr_counters_read(PtrContext *ctx, PtrCounters *out) {
     if (!out) return set_err(PTR_ERR_INVALID, "null out pointer");
     static_assert(sizeof(PtrCounters) == C_COUNT * sizeof(uint64_t), "counter layout");
     if ((rc = sync_all(ctx))) return rc;
-    HIPCHK(hipMemcpy(out, ctx->ctrs, sizeof(PtrCounters), hipMemcpyDeviceToHost));
+    unsigned long long copies[CTR_REPLICAS * CTR_STRIDE];
+    HIPCHK(hipMemcpy(copies, ctx->ctrs, sizeof(copies), hipMemcpyDeviceToHost));
+    uint64_t *sum = reinterpret_cast<uint64_t *>(out);
+    for (int c = 0; c < C_COUNT; c++) {
+        sum[c] = 0;
+        for (int r = 0; r < CTR_REPLICAS; r++) sum[c] += copies[r * CTR_STRIDE + c];
+    }
     out->camera_rays = ctx->camera_rays;
     return PTR_OK;
 }
@@ -1011,7 +1017,7 @@ int ptr_counters_reset(PtrContext *ctx) {
     int rc = ctx_use(ctx);
     if (rc) return rc;
     if ((rc = sync_all(ctx))) return rc;
-    HIPCHK(hipMemset(ctx->ctrs, 0, C_COUNT * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(ctx->ctrs, 0, CTR_REPLICAS * CTR_STRIDE * sizeof(unsigned long long)));
     HIPCHK(hipDeviceSynchronize());
     ctx->camera_rays = 0;
     return PTR_OK;

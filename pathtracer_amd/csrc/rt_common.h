@@ -67,9 +67,14 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+/* The counters exist CTR_REPLICAS times, each copy in a 128-byte line of its own, and a block adds to the copy
+ * its index selects: thousands of wavefronts flushing into ONE line at the end of every launch queue up behind
+ * each other (atomics on a line are served one at a time).  ptr_counters_read sums the copies. */
+#define CTR_REPLICAS 32
+#define CTR_STRIDE 16 /* unsigned long longs per copy: 128 B >= C_COUNT counters */
 __device__ __forceinline__ void ctr_flush(unsigned long long *ctrs, int idx, unsigned v) {
     unsigned s = wave_sum(v);
-    if (__lane_id() == 0 && s) atomicAdd(&ctrs[idx], (unsigned long long)s);
+    if (__lane_id() == 0 && s) atomicAdd(&ctrs[(blockIdx.x & (CTR_REPLICAS - 1)) * CTR_STRIDE + idx], (unsigned long long)s);
 }
 /* wave-aggregated append: one atomic per wavefront */
 __device__ __forceinline__ void queue_append(int *counter, int *queue, bool pred, int value) {
@@ -90,6 +95,7 @@ __device__ __forceinline__ void queue_append(int *counter, int *queue, bool pred
 enum { ROUTE_NEXT = 1, ROUTE_NEE = 2, ROUTE_SHADOW = 4, ROUTE_MIS = 8 };
 
 enum { C_TOTAL = 0, C_MISS, C_SURF, C_MED, C_LIGHT, C_ZERO, C_SHADOW, C_MIS, C_PROBE, C_CAMERA, C_NODES, C_PRIMS, C_COUNT };
+static_assert(C_COUNT <= CTR_STRIDE, "a counter copy is one 128-byte line");
 
 /* grid-stride helper: every lane of a wavefront runs the same number of rounds, so the ballots of
  * queue_append / ctr_flush stay convergent; n may live in device memory (written by an earlier
