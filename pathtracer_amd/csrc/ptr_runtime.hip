@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(TPB) k_raygen_only(DCamera cam, PassParams prm
  * compacted, in order, into the queue the shade kernel reads, so that its wavefronts hold only
  * vertices that run the surface / medium code: from the second bounce on about half of all rays
  * escape to the sky, and a shade wavefront costs the same whether 30 or 64 of its lanes hit. */
-#define MISS_CHUNK 8 /* groups of 64 queue entries a wavefront handles per reservation in the output queue */
+#define MISS_CHUNK 16 /* groups of 64 queue entries a wavefront handles per reservation in the output queue */
 __global__ void __launch_bounds__(TPB) k_miss(DScene sc, Pipe pp, PassParams prm, const int *n_ptr, int n_host, const int *queue, int *q_hit,
                                               int *hit_count, unsigned long long *ctrs) {
     unsigned total = 0, miss = 0;
