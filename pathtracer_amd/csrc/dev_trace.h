@@ -54,6 +54,10 @@ enum { TM_IDLE = 0, TM_TOP = 1, TM_TOPLEAF = 2, TM_GEOM = 3 };
 #ifndef PT_POOL
 #define PT_POOL 64
 #endif
+/* lanes that want a top-level step wait until this many do */
+#ifndef PT_TOP_BATCH
+#define PT_TOP_BATCH 16
+#endif
 /* idle lanes wait until this many can be refilled together */
 #ifndef PT_REFILL
 #define PT_REFILL 24
@@ -215,7 +219,12 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, unsigned *total
             if (exhausted && __ballot(mode != TM_IDLE) == 0) break; /* every wave reaches this: the grid drains */
         }
 
-        /* ---- top level: the reference's own tree, step for step (primitive.cpp:374-431) ---- */
+        /* ---- top level: the reference's own tree, step for step (primitive.cpp:374-431) ----
+         * Lanes that come back from a mesh need a few more steps up here (leave the leaf, pop, maybe finish);
+         * run for two or three lanes, those steps would hold up every lane that is inside a mesh.  So they wait
+         * until PT_TOP_BATCH lanes want the top level (a refill brings PT_REFILL at once) or nobody is in a mesh. */
+        const unsigned long long in_top = __ballot(mode == TM_TOP || mode == TM_TOPLEAF);
+        if (__popcll(in_top) >= PT_TOP_BATCH || __ballot(mode == TM_GEOM) == 0)
         while (mode == TM_TOP || mode == TM_TOPLEAF) {
             if (mode == TM_TOP) {
                 if (tnode == -1) { PT_FINISH(); break; }
