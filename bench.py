@@ -180,21 +180,23 @@ def main():
 
     if rank == 0:
         # dominant kernel: k_ptrace<false,false>, the closest-hit persistent tracer, launched for the path segments
-        # ("trace_closest") and for the MIS rays of direct lighting ("nee_mis")
+        # ("trace_closest") and - unless the library can answer them with any-hit rays ("nee_mis_any": scenes without emitting
+        # primitives and media, like this one) - for the MIS rays of direct lighting ("nee_mis")
         def closest(p):
             return p["trace_closest"]["launches"] + p["nee_mis"]["launches"], p["trace_closest"]["total_ms"] + p["nee_mis"]["total_ms"]
-        traced = max(1, cc["total_paths"] + cc["mis_rays"])  # counting pass: every one of them went through the counting variant
+        mis_closest = 1 if profx["nee_mis"]["launches"] > 0 else 0
+        traced = max(1, cc["total_paths"] + mis_closest * cc["mis_rays"])  # counting pass: every one of them went through the counting variant
         nodes_per_ray = cc["nodes_visited"] / traced
         items_per_ray = cc["prims_tested"] / traced
         bytes_per_ray = 64.0 + 32.0 * nodes_per_ray + 48.0 * items_per_ray
         launches, total_ms = closest(profx)
         launches = max(1, launches)
         avg_ms = total_ms / launches
-        rays_per_launch = (cx["total_paths"] + cx["mis_rays"]) / launches  # incl. the ~3 % of segments the finish kernel traces itself
+        rays_per_launch = (cx["total_paths"] + mis_closest * cx["mis_rays"]) / launches  # incl. the ~3 % of segments the finish kernel traces itself
         achieved = bytes_per_ray * rays_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         t_launches, t_ms = closest(prof)
         t_avg_ms = t_ms / max(1, t_launches)
-        t_rays_per_launch = (c["total_paths"] + c["mis_rays"]) / max(1, t_launches)
+        t_rays_per_launch = (c["total_paths"] + mis_closest * c["mis_rays"]) / max(1, t_launches)
         t_achieved = bytes_per_ray * t_rays_per_launch / (t_avg_ms * 1e-3) / 1e9 if t_avg_ms > 0 else 0.0
         traffic, traffic_src = measured_traffic("k_ptrace<false, false>")
         out = {

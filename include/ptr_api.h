@@ -205,7 +205,7 @@ typedef struct {
 } PtrCounters;
 
 /* One entry per kernel family; filled by ptr_profile_read when profiling is on. */
-#define PTR_PROF_KERNELS 9
+#define PTR_PROF_KERNELS 10
 typedef struct {
     char name[32];
     uint64_t launches;

@@ -34,6 +34,7 @@ struct TraceIO {
      * tile_words = words per record (0: the byte strides above apply), o / prim = the plane base,
      * w_o, w_d, w_prim, w_t = first word of origin, direction, prim result, t result (-1: none) */
     int tile_words, w_o, w_d, w_prim, w_t;
+    int any_as_hit; /* any-hit launch whose result is read like a closest hit's prim word: some prim id / -1 */
 };
 
 enum { TM_IDLE = 0, TM_TOP = 1, TM_TOPLEAF = 2, TM_GEOM = 3 };
@@ -85,7 +86,7 @@ template <bool COUNT>
 PD void trace_io_store(const TraceIO &io, bool any, int slot, bool hit, int hp, int hf, float tmax, float hb0, float hb1, unsigned rn, unsigned ri) {
     if (io.tile_words) {
         int *b = reinterpret_cast<int *>(io.prim);
-        b[plane_at(io.tile_words, slot, io.w_prim)] = any ? (hit ? 1 : 0) : (hit ? hp : -1);
+        b[plane_at(io.tile_words, slot, io.w_prim)] = (any && !io.any_as_hit) ? (hit ? 1 : 0) : (hit ? hp : -1);
         if (!any && io.w_t >= 0) b[plane_at(io.tile_words, slot, io.w_t)] = __float_as_int(tmax);
         return;
     }

@@ -291,9 +291,9 @@ static int set_err(int code, const std::string &msg) {
         if (e_ != hipSuccess) return set_err(PTR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-enum { K_RAYGEN = 0, K_TRACE, K_SHADE, K_SHADOW, K_MIS, K_RESOLVE, K_FILM, K_FINISH, K_MISS, K_API_TRACE = K_TRACE };
+enum { K_RAYGEN = 0, K_TRACE, K_SHADE, K_SHADOW, K_MIS, K_RESOLVE, K_FILM, K_FINISH, K_MISS, K_MIS_ANY, K_API_TRACE = K_TRACE };
 static const char *kKernelNames[PTR_PROF_KERNELS] = {"raygen", "trace_closest", "shade", "nee_shadow", "nee_mis", "nee_resolve", "film",
-                                                     "finish", "miss"};
+                                                     "finish", "miss", "nee_mis_any"};
 
 struct ProfSpan {
     hipEvent_t a, b;
@@ -329,6 +329,7 @@ struct PtrContext {
     /* one tracer launch per bounce for {next segments, shadow rays, MIS rays} instead of three: 6 % less GPU
      * time for a pass that has the GPU to itself, 2 % more when several passes overlap (bench.py): off by default */
     bool merge_traces = false;
+    bool mis_any_hit = true; /* MIS rays as any-hit rays where the result cannot tell the difference (PTR_MIS_ANY=0: never) */
     bool scene_has_sss = false; /* some material carries a BSSRDF: k_shade<true> / k_finish<true> */
     DCamera cam;
     int64_t bvh_bytes = 0;
@@ -623,7 +624,12 @@ static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int ste
             else { /* a launch per ray kind */
                 int *cnt = l.counts + 4 * k;
                 launch_ptrace(ctx, s, shadow_io(l, l.queues[3], cnt + 2, cursors + 3 * k + 1), upper_at(k), true, false, K_SHADOW);
-                launch_ptrace(ctx, s, mis_io(l, l.queues[4], cnt + 3, cursors + 3 * k + 2), upper_at(k), false, ctx->count_traversal, K_MIS);
+                /* The BSDF-sampled half of EstimateDirect asks what the ray hits first; when no primitive can emit and no
+                 * medium can attenuate, all nee_resolve_traced reads from the answer is whether anything was hit: any hit will do. */
+                TraceIO mio = mis_io(l, l.queues[4], cnt + 3, cursors + 3 * k + 2);
+                const bool mis_any = ctx->mis_any_hit && ctx->scene_all_opaque && !ctx->scene_has_media;
+                mio.any_as_hit = mis_any ? 1 : 0;
+                launch_ptrace(ctx, s, mio, upper_at(k), mis_any, ctx->count_traversal, mis_any ? K_MIS_ANY : K_MIS);
                 enqueue_resolve(ctx, l, upper_at(k), k);
             }
             q_cur = q_next;
@@ -699,6 +705,7 @@ int ptr_create(int device, PtrContext **out) {
         if (v > 0) { ctx->staged_bounces = v; ctx->staged_fixed = true; }
     }
     if (const char *e = getenv("PTR_MERGE")) ctx->merge_traces = atoi(e) != 0; /* tuning experiments */
+    if (const char *e = getenv("PTR_MIS_ANY")) ctx->mis_any_hit = atoi(e) != 0;
     if (const char *e = getenv("PTR_SPREAD")) { /* tuning experiments */
         int v = atoi(e);
         if (v > 0) ctx->spread = v;
