@@ -142,6 +142,22 @@ void KnotScene(Camera *camera, Float aspect, int segments, int variant) {
     InsertPrimitive(bottomWall, gray);
 }
 
+/* White furnace: one convex object inside a constant environment of radiance 1.  Nothing from the reference -
+ * a scene whose answer is known in closed form (tests/test_*_furnace.py): a convex Lambertian body shows its
+ * albedo, a mirror its reflectance, a non-absorbing dielectric exactly 1.
+ * variant: 0 matte 0.5 | 1 mirror 0.9 | 2 specular glass R = T = 1 | 3 rough glass | 4 matte box instead of a sphere */
+void FurnaceScene(Camera *camera, Float aspect, int variant) {
+    camera->Config(Point3f(0.f, 0.f, -6.f), Point3f(0.f, 0.f, 0.f), vec3f(0.f, 1.f, 0.f), 30.f, aspect);
+    static std::vector<Spectrum> sky(16 * 8, Spectrum(1.f));
+    InsertLightMap(sky.data(), 16, 8, RotateX(-90), Spectrum(1.0));
+    MaterialDescriptor mat = variant == 1 ? MakeMirrorMaterial(Spectrum(.9))
+                           : variant == 2 ? MakeGlassMaterial(Spectrum(1), Spectrum(1), 1.5)
+                           : variant == 3 ? MakeGlassMaterial(Spectrum(1), Spectrum(1), 1.5, .1, .1)
+                                          : MakeMatteMaterial(Spectrum(.5, .5, .5));
+    if (variant == 4) InsertPrimitive(MakeBox(RotateY(30) * RotateX(20), 1.4, 1.4, 1.4), mat);
+    else InsertPrimitive(MakeSphere(Translate(0, 0, 0), 1), mat);
+}
+
 /* material zoo on spheres/disks/rects under an area light + sky: exercises every BxDF the
  * materials instantiate (BoxesScene-like, main.cpp:489-570, small) */
 void ZooScene(Camera *camera, Float aspect, int variant) {
@@ -312,7 +328,7 @@ struct BuiltScene {
 
 extern "C" {
 
-/* name: "cornell" | "knot" | "zoo" | "volcaustic" | "fluid" | "subsurface" | "origami"; p0/p1: size and variant */
+/* name: "cornell" | "knot" | "zoo" | "volcaustic" | "fluid" | "subsurface" | "origami" | "furnace"; p0/p1: size and variant */
 void *pth_scene_build(const char *name, int width, int height, int p0, int p1) {
     std::string n(name);
     BuiltScene *b = new BuiltScene();
@@ -324,6 +340,7 @@ void *pth_scene_build(const char *name, int width, int height, int p0, int p1) {
     if (n == "cornell") CornellScene(&b->camera, aspect, p1);
     else if (n == "knot") KnotScene(&b->camera, aspect, p0 > 0 ? p0 : 660, p1);
     else if (n == "zoo") ZooScene(&b->camera, aspect, p1);
+    else if (n == "furnace") FurnaceScene(&b->camera, aspect, p1);
     else if (n == "volcaustic") VolumetricCausticsScene(&b->camera, aspect);
     else if (n == "fluid") FluidScene(&b->camera, aspect, p0 > 0 ? p0 : 4000000);
     else if (n == "subsurface") SubsurfaceScene(&b->camera, aspect, p0);
