@@ -145,7 +145,8 @@ void KnotScene(Camera *camera, Float aspect, int segments, int variant) {
 /* White furnace: one convex object inside a constant environment of radiance 1.  Nothing from the reference -
  * a scene whose answer is known in closed form (tests/test_*_furnace.py): a convex Lambertian body shows its
  * albedo, a mirror its reflectance, a non-absorbing dielectric exactly 1.
- * variant: 0 matte 0.5 | 1 mirror 0.9 | 2 specular glass R = T = 1 | 3 rough glass | 4 matte box instead of a sphere */
+ * variant: 0 matte 0.5 | 1 mirror 0.9 | 2 specular glass R = T = 1 | 3 rough glass | 4 matte box instead of a sphere |
+ * 5 a ball of purely scattering medium (sigma_a = 0: also exactly 1) | 6 matte octahedron as a triangle mesh */
 void FurnaceScene(Camera *camera, Float aspect, int variant) {
     camera->Config(Point3f(0.f, 0.f, -6.f), Point3f(0.f, 0.f, 0.f), vec3f(0.f, 1.f, 0.f), 30.f, aspect);
     static std::vector<Spectrum> sky(16 * 8, Spectrum(1.f));
@@ -155,7 +156,15 @@ void FurnaceScene(Camera *camera, Float aspect, int variant) {
                            : variant == 3 ? MakeGlassMaterial(Spectrum(1), Spectrum(1), 1.5, .1, .1)
                                           : MakeMatteMaterial(Spectrum(.5, .5, .5));
     if (variant == 4) InsertPrimitive(MakeBox(RotateY(30) * RotateX(20), 1.4, 1.4, 1.4), mat);
-    else InsertPrimitive(MakeSphere(Translate(0, 0, 0), 1), mat);
+    else if (variant == 5) InsertPrimitive(MakeSphere(Translate(0, 0, 0), 1), MakeMedium(Spectrum(0.f), Spectrum(.8f), 0.3f));
+    else if (variant == 6) {
+        static Point3f P[6] = {Point3f(1, 0, 0), Point3f(-1, 0, 0), Point3f(0, 1, 0), Point3f(0, -1, 0), Point3f(0, 0, 1), Point3f(0, 0, -1)};
+        static Point3i I[24];
+        const int f[8][3] = {{0, 2, 4}, {2, 1, 4}, {1, 3, 4}, {3, 0, 4}, {2, 0, 5}, {1, 2, 5}, {3, 1, 5}, {0, 3, 5}};
+        for (int t = 0; t < 8; t++)
+            for (int c = 0; c < 3; c++) I[3 * t + c] = Point3i(f[t][c], -1, -1);
+        InsertPrimitive(MakeMesh(ParsedMeshFromData(RotateY(25) * RotateX(15), 8, I, 6, P)), mat);
+    } else InsertPrimitive(MakeSphere(Translate(0, 0, 0), 1), mat);
 }
 
 /* material zoo on spheres/disks/rects under an area light + sky: exercises every BxDF the

@@ -18,6 +18,9 @@ CASES = {
     "mirror_sphere": (1, 0.9, ("path", "pathsampled", "volpath"), 0.01),
     # specular glass: Fresnel reflection + transmission add up to 1 at every interface, nothing is absorbed
     "glass_sphere": (2, 1.0, ("path", "pathsampled", "volpath"), 0.02),
+    "matte_mesh": (6, 0.5, ("direct", "path", "pathsampled", "volpath"), 0.01),
+    # a ball of medium that only scatters (sigma_a = 0, g = 0.3): every photon that goes in comes out
+    "scattering_ball": (5, 1.0, ("volpath",), 0.02),
 }
 INTEGRATORS = {"direct": pa.LI_DIRECT, "path": pa.LI_PATH, "pathsampled": pa.LI_PATHSAMPLED, "volpath": pa.LI_VOLPATH}
 
