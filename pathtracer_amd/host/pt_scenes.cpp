@@ -146,9 +146,20 @@ void KnotScene(Camera *camera, Float aspect, int segments, int variant) {
  * a scene whose answer is known in closed form (tests/test_*_furnace.py): a convex Lambertian body shows its
  * albedo, a mirror its reflectance, a non-absorbing dielectric exactly 1.
  * variant: 0 matte 0.5 | 1 mirror 0.9 | 2 specular glass R = T = 1 | 3 rough glass | 4 matte box instead of a sphere |
- * 5 a ball of purely scattering medium (sigma_a = 0: also exactly 1) | 6 matte octahedron as a triangle mesh */
+ * 5 a ball of purely scattering medium (sigma_a = 0: also exactly 1) | 6 matte octahedron as a triangle mesh |
+ * 7 a matte floor under a sky that is 1 above the horizon and 0 below (irradiance pi -> the floor shows its albedo;
+ *   the light map is anything but uniform, so this goes through the Distribution2D importance sampling) */
 void FurnaceScene(Camera *camera, Float aspect, int variant) {
     camera->Config(Point3f(0.f, 0.f, -6.f), Point3f(0.f, 0.f, 0.f), vec3f(0.f, 1.f, 0.f), 30.f, aspect);
+    if (variant == 7) {
+        camera->Config(Point3f(0.f, 4.f, -6.f), Point3f(0.f, 0.f, 0.f), vec3f(0.f, 1.f, 0.f), 20.f, aspect);
+        static std::vector<Spectrum> half(64 * 32);
+        for (int v = 0; v < 32; v++)
+            for (int u = 0; u < 64; u++) half[(size_t)v * 64 + u] = Spectrum(v < 16 ? 1.f : 0.f); /* theta < pi/2: the light's +z side */
+        InsertLightMap(half.data(), 64, 32, RotateX(-90), Spectrum(1.0));
+        InsertPrimitive(MakeRectangle(RotateX(90), 200, 200), MakeMatteMaterial(Spectrum(.5, .5, .5)));
+        return;
+    }
     static std::vector<Spectrum> sky(16 * 8, Spectrum(1.f));
     InsertLightMap(sky.data(), 16, 8, RotateX(-90), Spectrum(1.0));
     MaterialDescriptor mat = variant == 1 ? MakeMirrorMaterial(Spectrum(.9))
