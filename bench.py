@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--spp", type=int, default=16, help="samples per pixel per step and per GPU (one batch)")
+    ap.add_argument("--spp", type=int, default=32, help="samples per pixel per step and per GPU (one batch)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--segments", type=int, default=660, help="knot tessellation: 2*s*s triangles (660 -> 871,200)")

@@ -856,8 +856,9 @@ int ptr_film_init(PtrContext *ctx, int width, int height, uint64_t seed) {
         free_film(ctx);
         /* samples per pass: launches last as long as their longest ray (~2 ms on config[1]) while
          * the marginal cost is ~0.25 ns per ray, so a pass should carry tens of millions of path slots
-         * (config[1]: 16 M -> 1110, 32 M -> 1185, 64 M -> 1207 Mrays/s; ~300 B of HBM per slot and lane) */
-        long long target = 1ll << 25;
+         * (config[1], end of round 1: 32 M -> 1578, 64 M -> 1658, 128 M -> 1694 Mrays/s; ~300 B of HBM per slot and lane,
+         * six lanes: 64 M slots = 117 GB of the 288 GB) */
+        long long target = 1ll << 26;
         if (const char *e = getenv("PTR_PASS_SLOTS")) { /* tuning experiments */
             long long v = atoll(e);
             if (v > 0) target = v;
@@ -866,7 +867,7 @@ int ptr_film_init(PtrContext *ctx, int width, int height, uint64_t seed) {
         if (nb < 1) nb = 1;
         if (nb > 64) nb = 64;
         size_t cap = (size_t)npix * nb;
-        if (cap > (size_t)1 << 30) return set_err(PTR_ERR_LIMIT, "film too large for one pass");
+        if (cap > (size_t)1 << 29) return set_err(PTR_ERR_LIMIT, "film too large for one pass"); /* 3 * cap is indexed with an int */
         ctx->nb_max = nb;
         HIPCHK(hipMalloc((void **)&ctx->we, 3 * sizeof(float) * npix));
         HIPCHK(hipMalloc((void **)&ctx->acc, sizeof(double) * npix));

@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--spp", type=int, default=16)
+    ap.add_argument("--spp", type=int, default=32)
     ap.add_argument("--passes", type=int, default=3)
     ap.add_argument("--integrator", type=int, default=3)
     ap.add_argument("--variant", type=int, default=0)
