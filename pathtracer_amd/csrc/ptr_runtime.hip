@@ -345,6 +345,7 @@ struct PtrContext {
     int next_lane = 0, last_film_lane = -1;
     int staged_bounces = 6; /* wavefront bounces before k_finish; adapted from the live counts of finished passes */
     bool staged_fixed = false;
+    int stage_div = 1024; /* a bounce is staged while more than slots / stage_div paths are alive (PTR_STAGE_DIV) */
     int spread = 1; /* a ptr_render call deals its samples to this many passes (lanes) */
     int *api_fetch = nullptr; /* ray-fetch cursors of the stand-alone trace entry points (rotating) */
     int api_fetch_next = 0;
@@ -561,11 +562,11 @@ static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int ste
     hipStream_t s = l.stream;
     const int slots = ctx->npix * nb;
     /* feedback: if the pass this lane ran before has completed, look at how fast it thinned out and
-     * stage bounces only while more than ~0.4 % of the paths are alive */
+     * stage bounces only while more than ~0.1 % of the paths are alive (at 64 M slots: 0.4 % -> 1654, 0.1 % -> 1707, 0.025 % -> 1689 Mrays/s) */
     if (!ctx->staged_fixed && l.staged_used > 0 && hipEventQuery(l.film_done) == hipSuccess) {
         const int *hc = l.counts_host; /* copied (async, pinned) at the end of that pass */
         int k = 0;
-        while (k < l.staged_used && hc[4 * k] > l.slots_used / 256) k++;
+        while (k < l.staged_used && hc[4 * k] > l.slots_used / ctx->stage_div) k++;
         /* all staged bounces were still wide: stage one more next time */
         ctx->staged_bounces = k < l.staged_used ? k + 1 : l.staged_used + 1;
     }
@@ -705,6 +706,7 @@ int ptr_create(int device, PtrContext **out) {
         if (v > 0) { ctx->staged_bounces = v; ctx->staged_fixed = true; }
     }
     if (const char *e = getenv("PTR_MERGE")) ctx->merge_traces = atoi(e) != 0; /* tuning experiments */
+    if (const char *e = getenv("PTR_STAGE_DIV")) { int v = atoi(e); if (v > 0) ctx->stage_div = v; }
     if (const char *e = getenv("PTR_MIS_ANY")) ctx->mis_any_hit = atoi(e) != 0;
     if (const char *e = getenv("PTR_SPREAD")) { /* tuning experiments */
         int v = atoi(e);
