@@ -126,9 +126,17 @@ def main():
         # one batch on every rank: args.spp samples of every pixel (rank r takes the sample indices = r mod world)
         r.render(world * args.spp, args.integrator)
 
-    for _ in range(args.warmup):
-        step()
-    r.sync()
+    if args.roofline_only:
+        # The timed region is skipped and every pass runs alone (sync after each), so that a kernel trace of this mode
+        # (profiles/*_exclusive_*) holds nothing but launches that had the GPU to themselves.  The library's adaptive
+        # staging depth gets the passes it would have seen in the timed region, so the launches are those of a full run.
+        for _ in range(args.warmup + args.steps):
+            step()
+            r.sync()
+    else:
+        for _ in range(args.warmup):
+            step()
+        r.sync()
 
     # untimed counting pass: child boxes / leaf items tested per traced ray (algorithmic bytes)
     r.counters_reset()
