@@ -216,3 +216,36 @@ def test_film_tensor_views_for_the_all_reduce(scenes):
     we_t.mul_(2.0)  # in place on the device: visible through ptr_film_read
     torch.cuda.synchronize()
     assert np.array_equal(r.film()[0], we * 2)
+
+
+def test_thin_lens_camera(cuda):
+    """Camera::Config with an aperture (camera.cpp:145-197, SpawnRay 219-229): lens samples move the ray origin; no
+    shipped scene family uses it, so the rays and an image are compared on a scene assembled here."""
+    from pathtracer_amd import scene as S
+    b = pa.FlatSceneBuilder()
+    b.rectangle(12, 12, pa.material("matte", kd=(0.6, 0.6, 0.6)), to_world=S.rotate_x(-90))
+    b.sphere(0.7, pa.material("plastic", kd=(0.7, 0.2, 0.2)), to_world=S.translate(-0.8, 0.7, 0.5))
+    b.sphere(0.5, pa.material("glass", index=1.5), to_world=S.translate(0.9, 0.5, -1.0))
+    b.rectangle(2, 2, pa.material("emissive", L=(12, 12, 12)), to_world=S.translate(0, 4, 0) @ S.rotate_x(90))
+    sc = b.finish()
+    cam = pa.look_at_camera((0, 1.8, -5), (0, 0.5, 0), (0, 1, 0), 35, W / H, aperture=0.4)
+    assert cam.lens_radius > 0
+    o = orc.OracleScene(sc.flat, 0)
+    with pa.Renderer(0) as r:
+        r.upload(sc)
+        r.set_camera(cam)
+        r.film_init(W, H, SEED)
+        for sample in (0, 3):
+            go, gd, gw = common.gpu_generate_rays(r, W * H, sample)
+            oo, od, ow = o.generate_rays(cam, W, H, SEED, sample)
+            assert np.ptp(oo, axis=1).max() > 0.05  # origins really are spread over the lens
+            # device cosf / sinf of the lens sample enter the origin: ulps, not bit-exact
+            assert np.allclose(go, oo, rtol=1e-5, atol=1e-6) and np.allclose(gd, od, rtol=1e-5, atol=1e-6)
+            assert np.allclose(gw, ow, rtol=1e-5, atol=1e-7)
+        r.render(8, pa.LI_PATHSAMPLED)
+        img = r.image()
+        we, acc, _ = o.render(cam, W, H, SEED, 0, 8, pa.LI_PATHSAMPLED, 8)
+        ref = orc.image_of(we, acc).reshape(H, W, 3)
+        mean_rel, rmse_rel, off = common.image_stats(img, ref)
+        assert mean_rel < 5e-3 and rmse_rel < 5e-2 and off < 0.02, (mean_rel, rmse_rel, off)
+    o.close()
