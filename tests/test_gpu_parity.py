@@ -249,3 +249,43 @@ def test_thin_lens_camera(cuda):
         mean_rel, rmse_rel, off = common.image_stats(img, ref)
         assert mean_rel < 5e-3 and rmse_rel < 5e-2 and off < 0.02, (mean_rel, rmse_rel, off)
     o.close()
+
+
+def test_caller_stream(scenes):
+    """ptr_set_stream: the stand-alone trace runs on the caller's stream, and work the caller queues there after
+    ptr_render sees the finished film without a host sync in between (the lanes' streams are joined into it)."""
+    import torch
+    from pathtracer_amd import dist as pdist
+    sc, o, r = scenes("knot_plastic")
+    dev = torch.device("cuda:0")
+    oo, od, _ = o.generate_rays(sc.camera, W, H, SEED, 0)
+    tmax = np.full(W * H, FMAX, np.float32)
+    want = common.gpu_trace_closest(r, oo, od, tmax)  # on the context's default stream
+    s = torch.cuda.Stream(device=dev)
+    r.set_stream(s.cuda_stream)
+    try:
+        with torch.cuda.stream(s):
+            n = W * H
+            to = torch.from_numpy(oo).to(dev, non_blocking=True)
+            td = torch.from_numpy(od).to(dev, non_blocking=True)
+            tt = torch.from_numpy(tmax).to(dev, non_blocking=True)
+            prim = torch.full((n,), -7, dtype=torch.int32, device=dev)
+            face = torch.empty(n, dtype=torch.int32, device=dev)
+            t = torch.empty(n, dtype=torch.float32, device=dev)
+            r.trace_closest(n, to.data_ptr(), td.data_ptr(), tt.data_ptr(), prim.data_ptr(), face.data_ptr(), t.data_ptr())
+            got_prim = prim.clone()  # ordered after the trace by the stream alone
+        s.synchronize()
+        assert np.array_equal(got_prim.cpu().numpy(), want["prim"])
+        assert np.array_equal(t.cpu().numpy(), want["t"])
+
+        r.film_init(W, H, SEED)
+        we_t, acc_t, smp_t = pdist.film_tensors(r, dev)
+        with torch.cuda.stream(s):
+            r.render(6, pa.LI_PATH)
+            early = we_t.double().sum()  # queued on the caller's stream right behind the render, no host sync
+        s.synchronize()
+        r.sync()
+        assert float(early) == float(we_t.double().sum()) and float(early) > 0
+        assert int(smp_t.min()) == 6
+    finally:
+        r.set_stream(0)
