@@ -150,6 +150,29 @@ struct ThreeSources {
     }
 };
 
+/* Two any-hit queues in one launch: the shadow rays and - where any hit answers them (ptr_runtime.hip) - the MIS rays of a bounce */
+struct TwoAny {
+    TraceIO a, b; /* a.counter is the fetch cursor of the launch */
+    int n0, n01;
+    int *counter;
+    PD void init() {
+        n0 = a.n_ptr ? *a.n_ptr : a.n;
+        n01 = n0 + (b.n_ptr ? *b.n_ptr : b.n);
+        counter = a.counter;
+    }
+    PD int total() const { return n01; }
+    PD bool is_any(int) const { return true; }
+    PD void fetch(int idx, int *tag, int *slot, f3 *ro, f3 *rd, float *tmax) const {
+        if (idx < n0) { *tag = 0; trace_io_fetch(a, idx, slot, ro, rd, tmax); }
+        else { *tag = 1; trace_io_fetch(b, idx - n0, slot, ro, rd, tmax); }
+    }
+    template <bool COUNT>
+    PD void store(int tag, int slot, bool hit, int hp, int hf, float tmax, float hb0, float hb1, unsigned rn, unsigned ri) const {
+        if (tag == 0) trace_io_store<COUNT>(a, true, slot, hit, hp, hf, tmax, hb0, hb1, rn, ri);
+        else trace_io_store<COUNT>(b, true, slot, hit, hp, hf, tmax, hb0, hb1, rn, ri);
+    }
+};
+
 template <class Source, bool COUNT>
 PD void persistent_trace(const DScene &sc, Source src, int *lds, unsigned *total_nodes, unsigned *total_items) {
     int ovf[OVF_STACK];

@@ -329,6 +329,7 @@ struct PtrContext {
     /* one tracer launch per bounce for {next segments, shadow rays, MIS rays} instead of three: 6 % less GPU
      * time for a pass that has the GPU to itself, 2 % more when several passes overlap (bench.py): off by default */
     bool merge_traces = false;
+    bool nee_one_launch = false; /* shadow + any-hit MIS rays of a bounce in one launch (PTR_NEE_ONE) */
     bool mis_any_hit = true; /* MIS rays as any-hit rays where the result cannot tell the difference (PTR_MIS_ANY=0: never) */
     bool scene_has_sss = false; /* some material carries a BSSRDF: k_shade<true> / k_finish<true> */
     DCamera cam;
@@ -624,13 +625,19 @@ static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int ste
             if (walks) enqueue_nee_walks(ctx, l, upper_at(k), k);
             else { /* a launch per ray kind */
                 int *cnt = l.counts + 4 * k;
-                launch_ptrace(ctx, s, shadow_io(l, l.queues[3], cnt + 2, cursors + 3 * k + 1), upper_at(k), true, false, K_SHADOW);
                 /* The BSDF-sampled half of EstimateDirect asks what the ray hits first; when no primitive can emit and no
                  * medium can attenuate, all nee_resolve_traced reads from the answer is whether anything was hit: any hit will do. */
                 TraceIO mio = mis_io(l, l.queues[4], cnt + 3, cursors + 3 * k + 2);
                 const bool mis_any = ctx->mis_any_hit && ctx->scene_all_opaque && !ctx->scene_has_media;
                 mio.any_as_hit = mis_any ? 1 : 0;
+                if (mis_any && ctx->nee_one_launch) {
+                    ProfScope ps(ctx, s, K_SHADOW, 0);
+                    rt_launch_ptrace2any(clampu(nblocks(2 * upper_at(k)), 1, (unsigned)ctx->persist_blocks), s, ctx->sc,
+                                         shadow_io(l, l.queues[3], cnt + 2, cursors + 3 * k + 1), mio);
+                } else {
+                launch_ptrace(ctx, s, shadow_io(l, l.queues[3], cnt + 2, cursors + 3 * k + 1), upper_at(k), true, false, K_SHADOW);
                 launch_ptrace(ctx, s, mio, upper_at(k), mis_any, ctx->count_traversal, mis_any ? K_MIS_ANY : K_MIS);
+                }
                 enqueue_resolve(ctx, l, upper_at(k), k);
             }
             q_cur = q_next;
@@ -706,6 +713,7 @@ int ptr_create(int device, PtrContext **out) {
         if (v > 0) { ctx->staged_bounces = v; ctx->staged_fixed = true; }
     }
     if (const char *e = getenv("PTR_MERGE")) ctx->merge_traces = atoi(e) != 0; /* tuning experiments */
+    if (const char *e = getenv("PTR_NEE_ONE")) ctx->nee_one_launch = atoi(e) != 0;
     if (const char *e = getenv("PTR_STAGE_DIV")) { int v = atoi(e); if (v > 0) ctx->stage_div = v; }
     if (const char *e = getenv("PTR_MIS_ANY")) ctx->mis_any_hit = atoi(e) != 0;
     if (const char *e = getenv("PTR_SPREAD")) { /* tuning experiments */

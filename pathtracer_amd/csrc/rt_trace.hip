@@ -35,6 +35,18 @@ k_ptrace3(DScene sc, TraceIO path, TraceIO shadow, TraceIO mis, unsigned long lo
     }
 }
 
+__global__ void __launch_bounds__(TRACE_TPB) __attribute__((amdgpu_waves_per_eu(PT_WAVES, PT_WAVES))) k_ptrace2any(DScene sc, TraceIO a, TraceIO b) {
+    __shared__ int s_stack[LDS_STACK * TRACE_TPB];
+    unsigned tn = 0, ti = 0;
+    TwoAny src;
+    src.a = a;
+    src.b = b;
+    persistent_trace<TwoAny, false>(sc, src, &s_stack[threadIdx.x], &tn, &ti);
+}
+void rt_launch_ptrace2any(unsigned blocks, hipStream_t s, const DScene &sc, const TraceIO &a, const TraceIO &b) {
+    hipLaunchKernelGGL(k_ptrace2any, dim3(blocks), dim3(TRACE_TPB), 0, s, sc, a, b);
+}
+
 void rt_launch_ptrace3(bool count, unsigned blocks, hipStream_t s, const DScene &sc, const TraceIO &path, const TraceIO &shadow, const TraceIO &mis,
                        unsigned long long *ctrs) {
     if (count) hipLaunchKernelGGL((k_ptrace3<true>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, path, shadow, mis, ctrs);
