@@ -84,16 +84,16 @@ PD bool slab_minmax(float mnx, float mny, float mnz, float mxx, float mxy, float
     } while (0)
 PD int bvh4_visit(const Node128 *nodes, int node, const f3 &ro, const f3 &inv, float tmax, int &r0, int &r1, int &r2, int &r3, unsigned *tested) {
     const float4 *np = reinterpret_cast<const float4 *>(nodes + node);
-    const float4 mnx = np[0], mny = np[1], mnz = np[2], mxx = np[3], mxy = np[4], mxz = np[5];
-    const float4 chf = np[6];
-    r0 = __float_as_int(chf.x); r1 = __float_as_int(chf.y); r2 = __float_as_int(chf.z); r3 = __float_as_int(chf.w);
+    /* child i = np[2 i] (min xyz, max x), np[2 i + 1] (max y, max z, ref, -) */
+    const float4 a0 = np[0], b0 = np[1], a1 = np[2], b1 = np[3], a2 = np[4], b2 = np[5], a3 = np[6], b3 = np[7];
+    r0 = __float_as_int(b0.z); r1 = __float_as_int(b1.z); r2 = __float_as_int(b2.z); r3 = __float_as_int(b3.z);
     float t0 = kInfinity, t1 = kInfinity, t2 = kInfinity, t3 = kInfinity;
     if (tested) *tested += (r0 != BVH_NO_CHILD) + (r1 != BVH_NO_CHILD) + (r2 != BVH_NO_CHILD) + (r3 != BVH_NO_CHILD);
     {
-        const bool h0 = slab_minmax(mnx.x, mny.x, mnz.x, mxx.x, mxy.x, mxz.x, ro, inv, tmax, &t0) & (r0 != BVH_NO_CHILD);
-        const bool h1 = slab_minmax(mnx.y, mny.y, mnz.y, mxx.y, mxy.y, mxz.y, ro, inv, tmax, &t1) & (r1 != BVH_NO_CHILD);
-        const bool h2 = slab_minmax(mnx.z, mny.z, mnz.z, mxx.z, mxy.z, mxz.z, ro, inv, tmax, &t2) & (r2 != BVH_NO_CHILD);
-        const bool h3 = slab_minmax(mnx.w, mny.w, mnz.w, mxx.w, mxy.w, mxz.w, ro, inv, tmax, &t3) & (r3 != BVH_NO_CHILD);
+        const bool h0 = slab_minmax(a0.x, a0.y, a0.z, a0.w, b0.x, b0.y, ro, inv, tmax, &t0) & (r0 != BVH_NO_CHILD);
+        const bool h1 = slab_minmax(a1.x, a1.y, a1.z, a1.w, b1.x, b1.y, ro, inv, tmax, &t1) & (r1 != BVH_NO_CHILD);
+        const bool h2 = slab_minmax(a2.x, a2.y, a2.z, a2.w, b2.x, b2.y, ro, inv, tmax, &t2) & (r2 != BVH_NO_CHILD);
+        const bool h3 = slab_minmax(a3.x, a3.y, a3.z, a3.w, b3.x, b3.y, ro, inv, tmax, &t3) & (r3 != BVH_NO_CHILD);
         r0 = h0 ? r0 : BVH_NO_CHILD; t0 = h0 ? t0 : kInfinity;
         r1 = h1 ? r1 : BVH_NO_CHILD; t1 = h1 ? t1 : kInfinity;
         r2 = h2 ? r2 : BVH_NO_CHILD; t2 = h2 ? t2 : kInfinity;
@@ -370,7 +370,9 @@ struct TraceStats { unsigned nodes, items; };
 /* Per-lane traversal stack: the first LDS_STACK entries live in LDS (column threadIdx.x of a
  * [LDS_STACK][block] array: conflict-free, and a pop no longer waits on a scratch load), deeper
  * entries spill to a small scratch array that well-built trees rarely reach. */
+#ifndef LDS_STACK
 #define LDS_STACK 24
+#endif
 #define OVF_STACK (BVH_STACK - LDS_STACK)
 #define TRACE_TPB 256
 struct LaneStack {

@@ -11,15 +11,19 @@ enum { PF_FLIP_N = 1, PF_REVERSE = 2, PF_EMISSIVE = 4 };
 enum { ITEM_TRI = 0, ITEM_PARTICLE = 1, ITEM_PRIM = 2 };
 enum { LT_AREA = 1, LT_DISTANT = 2, LT_INFINITE = 3 };
 
-/* Inner node of a geometry BVH: FOUR children per node, 128 B = one L2 line.  Component planes of
- * the four child boxes (7 x float4 loads per visit), child refs: >= 0 inner node index, < 0 leaf
+/* Inner node of a geometry BVH: FOUR children per node, 128 B = one L2 line, child-major: child i is the
+ * 32-byte record c[i] = {box min xyz, box max xyz, ref, -}.  ref >= 0 inner node index, < 0 leaf
  * `-(first | (n-1) << 27) - 1` over items[], BVH_NO_CHILD = empty slot.  Made by collapsing the
  * binned-SAH binary tree (ptr_build.cpp): half as many dependent node fetches per ray as a binary
- * tree, and every byte of the fetched line is used. */
+ * tree, and every byte of the fetched line is used.  Child-major so that the four lanes that share a
+ * ray in the quad tracer (dev_qtrace.h) each fetch their child with two 16-byte loads; the one-ray-per-lane
+ * walkers read the whole line (dev_isect.h bvh4_visit). */
 struct Node128 {
-    float mnx[4], mny[4], mnz[4], mxx[4], mxy[4], mxz[4];
-    int32_t child[4];
-    int32_t pad[4];
+    struct Child {
+        float mn[3], mx[3];
+        int32_t ref;
+        int32_t pad;
+    } c[4];
 };
 /* Node of the top-level BVH over primitives: the reference's own tree (primitive.cpp:537-582),
  * kept because a few results depend on its visiting order.  Leaf: left = -1, handles

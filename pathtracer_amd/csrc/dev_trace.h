@@ -173,9 +173,33 @@ struct TwoAny {
     }
 };
 
+/* PT_STATS (diagnostic build only, tools/gpu_tracestats.py): where the lanes and the cycles of the persistent tracer go.
+ * Per phase: wave iterations, lanes active in them, shader cycles between the phase's first and last instruction. */
+#ifdef PT_STATS
+enum { PS_OUTER = 0, PS_REFILL_IT, PS_REFILL_LANES, PS_TOP_IT, PS_TOP_LANES, PS_IN_IT, PS_IN_LANES, PS_LEAF_IT, PS_LEAF_LANES, PS_LEAF_ENTRY, PS_LEAF_ENTRY_LANES,
+       PS_CYC_REFILL, PS_CYC_TOP, PS_CYC_IN, PS_CYC_LEAF, PS_CYC_TOTAL, PS_RAYS, PS_N };
+static __device__ unsigned long long g_pt_stats[PS_N];
+#define PS_ADD(k, v) do { st_[k] += (v); } while (0)
+/* inside divergent code: one active lane adds for the wave */
+#define PS_WAVE_IT(kit, klanes)                                                         \
+    do {                                                                                \
+        const unsigned long long m_ = __ballot(true);                                   \
+        if (lane == __ffsll((long long)m_) - 1) { atomicAdd(&g_pt_stats[kit], 1ull); atomicAdd(&g_pt_stats[klanes], (unsigned long long)__popcll(m_)); } \
+    } while (0)
+#define PS_CLOCK() clock64()
+#else
+#define PS_ADD(k, v) do { } while (0)
+#define PS_WAVE_IT(kit, klanes) do { } while (0)
+#define PS_CLOCK() 0ll
+#endif
+
 template <class Source, bool COUNT>
 PD void persistent_trace(const DScene &sc, Source src, int *lds, unsigned *total_nodes, unsigned *total_items) {
     int ovf[OVF_STACK];
+#ifdef PT_STATS
+    unsigned long long st_[PS_N] = {};
+    const long long t_begin_ = clock64();
+#endif
     const int lane = __lane_id();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
@@ -204,6 +228,8 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, unsigned *total
 #define PT_ANY (src.is_any(tag))
 
     for (;;) {
+        PS_ADD(PS_OUTER, 1);
+        const long long c0_ = PS_CLOCK();
         /* ---- refill idle lanes ---- */
         unsigned long long idle = __ballot(mode == TM_IDLE);
         /* refill in batches: the top-level phase a new ray starts with (analytic primitives: a
@@ -223,6 +249,7 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, unsigned *total
             if (avail > 0) {
                 const int rank = __popcll(idle & lt_mask);
                 if (mode == TM_IDLE && rank < avail) {
+                    PS_WAVE_IT(PS_REFILL_IT, PS_REFILL_LANES);
                     const int idx = pool_pos + rank;
                     src.fetch(idx, &tag, &slot, &ro, &rd, &tmax);
                     inv = f3(1 / rd.x, 1 / rd.y, 1 / rd.z);
@@ -247,9 +274,11 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, unsigned *total
          * Lanes that come back from a mesh need a few more steps up here (leave the leaf, pop, maybe finish);
          * run for two or three lanes, those steps would hold up every lane that is inside a mesh.  So they wait
          * until PT_TOP_BATCH lanes want the top level (a refill brings PT_REFILL at once) or nobody is in a mesh. */
+        const long long c1_ = PS_CLOCK();
         const unsigned long long in_top = __ballot(mode == TM_TOP || mode == TM_TOPLEAF);
         if (__popcll(in_top) >= PT_TOP_BATCH || __ballot(mode == TM_GEOM) == 0)
         while (mode == TM_TOP || mode == TM_TOPLEAF) {
+            PS_WAVE_IT(PS_TOP_IT, PS_TOP_LANES);
             if (mode == TM_TOP) {
                 if (tnode == -1) { PT_FINISH(); break; }
                 const TopNode &nd = sc.top[tnode];
@@ -304,7 +333,9 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, unsigned *total
         }
 
         /* ---- geometry level: inner nodes until a leaf ---- */
+        const long long c2_ = PS_CLOCK();
         while (mode == TM_GEOM && node >= 0) {
+            PS_WAVE_IT(PS_IN_IT, PS_IN_LANES);
             int r0, r1, r2, r3;
             const int nh = bvh4_visit(sc.nodes, node, ro, inv, tmax, r0, r1, r2, r3, COUNT ? &rn : nullptr);
             if (nh == 0) {
@@ -327,11 +358,14 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, unsigned *total
         }
 
         /* ---- leaf ---- */
+        const long long c3_ = PS_CLOCK();
         if (mode == TM_GEOM && node < 0) {
+            PS_WAVE_IT(PS_LEAF_ENTRY, PS_LEAF_ENTRY_LANES);
             unsigned packed = (unsigned)(-(node + 1));
             unsigned first = packed & 0x07FFFFFFu, n = (packed >> 27) + 1;
             bool ended = false;
             for (unsigned i = 0; i < n; i++) {
+                PS_WAVE_IT(PS_LEAF_IT, PS_LEAF_LANES);
                 const float4 *ip = reinterpret_cast<const float4 *>(sc.items + first + i);
                 float4 q0 = ip[0], q1 = ip[1], q2 = ip[2];
                 int kind = __float_as_int(q2.w);
@@ -356,7 +390,301 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, unsigned *total
             else if (sp == sp_base) mode = TM_TOPLEAF;
             else node = PT_POP();
         }
+#ifdef PT_STATS
+        const long long c4_ = clock64();
+        st_[PS_CYC_REFILL] += c1_ - c0_; st_[PS_CYC_TOP] += c2_ - c1_; st_[PS_CYC_IN] += c3_ - c2_; st_[PS_CYC_LEAF] += c4_ - c3_;
+#endif
     }
+#ifdef PT_STATS
+    st_[PS_CYC_TOTAL] = clock64() - t_begin_;
+    if (lane == 0) {
+        const int ks[] = {PS_OUTER, PS_CYC_REFILL, PS_CYC_TOP, PS_CYC_IN, PS_CYC_LEAF, PS_CYC_TOTAL};
+        for (int k : ks) atomicAdd(&g_pt_stats[k], st_[k]);
+    }
+#endif
 #undef PT_FINISH
 #undef PT_ANY
+}
+
+/* ---- fullest-phase-first scheduling -------------------------------------------------------------------
+ * persistent_trace above runs its phases one after the other in every round - top-level steps, inner nodes until
+ * few lanes are left in them, then the leaf items - each for the lanes that happen to be in it.  Measured on
+ * config[1] (tools/gpu_tracestats.py, PT_STATS build, r02): 44 / 26 / 24 % of the lanes are active in a top /
+ * inner / leaf iteration; a leaf phase starts with 19 of 64 lanes and loops over 1..4 items.  With lanes spread
+ * over four states and every state served once per round, a quarter of the lanes per phase is what that schedule gives.
+ *
+ * Here a round serves ONE phase: the one most lanes wait for (weighted by PT_W_*).  Lanes in the other states
+ * keep their state and wait; whatever is not served fills up until it is the fullest, so nothing starves, and
+ * a step runs with the largest group the wavefront has.  A step is one top-level iteration, one node visit, or
+ * ONE leaf item (the item loop is part of the state: no 1..4 trip count inside a step).  Same per-ray
+ * operations, in the same order per ray, as persistent_trace. */
+enum { TS_IDLE = 0, TS_TOP = 1, TS_TOPLEAF = 2, TS_IN = 3, TS_LEAF = 4 };
+#ifndef PT_W_TOP
+#define PT_W_TOP 4
+#endif
+#ifndef PT_W_IN
+#define PT_W_IN 4
+#endif
+#ifndef PT_W_LEAF
+#define PT_W_LEAF 4
+#endif
+#ifndef PT_W_IDLE
+#define PT_W_IDLE 4
+#endif
+/* hysteresis: the phase served last is served again while at least this many lanes are in it (0: always the fullest) */
+#ifndef PT_HYST
+#define PT_HYST 0
+#endif
+template <class Source, bool COUNT>
+PD void persistent_trace_sched(const DScene &sc, Source src, int *lds, unsigned *total_nodes, unsigned *total_items) {
+    int ovf[OVF_STACK];
+    const int lane = __lane_id();
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#ifdef PT_STATS
+    unsigned long long st_[PS_N] = {};
+    const long long t_begin_ = clock64();
+#endif
+
+    int mode = TS_IDLE, slot = -1, tag = 0;
+    src.init();
+    f3 ro, rd, inv;
+    TriRay tr;
+    tr.kx = tr.ky = tr.kz = 0; tr.Sx = tr.Sy = tr.Sz = 0;
+    float tmax = 0, hb0 = 0, hb1 = 0;
+    int hp = -1, hf = -1;
+    bool hit = false;
+    int tnode = -1, leaf_pos = 0, leaf_end = 0, cp = -1, node = 0, sp = 0, sp_base = 0;
+    unsigned it_pos = 0, it_end = 0; /* TS_LEAF: items left in the leaf */
+    unsigned rn = 0, ri = 0;
+
+    const int n_rays = src.total();
+    int pool_pos = 0, pool_end = 0; /* wave-uniform */
+    bool exhausted = false;
+    int last_pick = TS_IDLE; /* wave-uniform */
+
+#define PT_FINISH()                                                                  \
+    do {                                                                             \
+        src.template store<COUNT>(tag, slot, hit, hp, hf, tmax, hb0, hb1, rn, ri);   \
+        if (COUNT) { *total_nodes += rn; *total_items += ri; }                       \
+        mode = TS_IDLE;                                                              \
+        slot = -1;                                                                   \
+    } while (0)
+#define PT_ANY (src.is_any(tag))
+/* a geometry ref taken from a node or the stack: an inner node, or a leaf whose items become the lane's state */
+#define PT_ENTER(ref)                                                                \
+    do {                                                                             \
+        node = (ref);                                                                \
+        if (node >= 0) mode = TS_IN;                                                 \
+        else {                                                                       \
+            const unsigned packed_ = (unsigned)(-(node + 1));                        \
+            it_pos = packed_ & 0x07FFFFFFu;                                          \
+            it_end = it_pos + (packed_ >> 27) + 1;                                   \
+            mode = TS_LEAF;                                                          \
+        }                                                                            \
+    } while (0)
+/* the geometry BVH of the current primitive has nothing left for this ray: next primitive of the top-level leaf */
+#define PT_GEOM_NEXT()                                                               \
+    do {                                                                             \
+        if (sp == sp_base) mode = TS_TOPLEAF;                                        \
+        else { const int r_ = PT_POP(); PT_ENTER(r_); }                              \
+    } while (0)
+
+    for (;;) {
+        PS_ADD(PS_OUTER, 1);
+        const long long c0_ = PS_CLOCK();
+        const int n_idle = __popcll(__ballot(mode == TS_IDLE));
+        const int n_top = __popcll(__ballot(mode == TS_TOP || mode == TS_TOPLEAF));
+        const int n_in = __popcll(__ballot(mode == TS_IN));
+        const int n_leaf = __popcll(__ballot(mode == TS_LEAF));
+        const int w_top = n_top * PT_W_TOP, w_in = n_in * PT_W_IN, w_leaf = n_leaf * PT_W_LEAF;
+        const int w_busy = w_top > w_in ? (w_top > w_leaf ? w_top : w_leaf) : (w_in > w_leaf ? w_in : w_leaf);
+        if (n_idle == 64 && exhausted) break; /* every wave reaches this: the grid drains */
+
+        if (!exhausted && n_idle > 0 && n_idle * PT_W_IDLE >= w_busy) {
+            /* ---- refill idle lanes ---- */
+            if (pool_pos >= pool_end) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(src.counter, PT_POOL);
+                base = __shfl(base, 0, 64);
+                if (base >= n_rays) exhausted = true;
+                else {
+                    pool_pos = base;
+                    pool_end = base + PT_POOL < n_rays ? base + PT_POOL : n_rays;
+                }
+            }
+            const int avail = pool_end - pool_pos;
+            if (avail > 0) {
+                const unsigned long long idle = __ballot(mode == TS_IDLE);
+                const int rank = __popcll(idle & lt_mask);
+                if (mode == TS_IDLE && rank < avail) {
+                    PS_WAVE_IT(PS_REFILL_IT, PS_REFILL_LANES);
+                    const int idx = pool_pos + rank;
+                    src.fetch(idx, &tag, &slot, &ro, &rd, &tmax);
+                    inv = f3(1 / rd.x, 1 / rd.y, 1 / rd.z);
+                    tr = tri_ray_setup(rd);
+                    hp = -1; hf = -1; hb0 = 0; hb1 = 0; hit = false;
+                    rn = 0; ri = 0;
+                    sp = 0;
+                    if (sc.n_top == 0) PT_FINISH();
+                    else {
+                        PT_PUSH(-1);
+                        tnode = 0;
+                        mode = TS_TOP;
+                    }
+                }
+                pool_pos += n_idle < avail ? n_idle : avail;
+            }
+#ifdef PT_STATS
+            st_[PS_CYC_REFILL] += clock64() - c0_;
+#endif
+            continue;
+        }
+
+        int pick = (w_in >= w_leaf && w_in >= w_top) ? TS_IN : (w_leaf >= w_top ? TS_LEAF : TS_TOP);
+        if (PT_HYST > 0) {
+            const int n_last = last_pick == TS_IN ? n_in : (last_pick == TS_LEAF ? n_leaf : (last_pick == TS_TOP ? n_top : 0));
+            if (n_last >= PT_HYST) pick = last_pick;
+            last_pick = pick;
+        }
+        if (pick == TS_IN) {
+            /* ---- one node visit of the geometry BVH ---- */
+            if (mode == TS_IN) {
+                PS_WAVE_IT(PS_IN_IT, PS_IN_LANES);
+                int r0, r1, r2, r3;
+                const int nh = bvh4_visit(sc.nodes, node, ro, inv, tmax, r0, r1, r2, r3, COUNT ? &rn : nullptr);
+                if (nh == 0) PT_GEOM_NEXT();
+                else {
+                    if (sp + 3 <= LDS_STACK) { /* the usual case: three unconditional LDS stores, farthest child deepest */
+                        lds[sp * TRACE_TPB] = nh == 4 ? r3 : (nh == 3 ? r2 : r1);
+                        lds[(sp + 1) * TRACE_TPB] = nh == 4 ? r2 : r1;
+                        lds[(sp + 2) * TRACE_TPB] = r1;
+                        sp += nh - 1;
+                    } else {
+                        if (nh > 3) PT_PUSH(r3);
+                        if (nh > 2) PT_PUSH(r2);
+                        if (nh > 1) PT_PUSH(r1);
+                    }
+                    PT_ENTER(r0);
+                }
+            }
+#ifdef PT_STATS
+            st_[PS_CYC_IN] += clock64() - c0_;
+#endif
+        } else if (pick == TS_LEAF) {
+            /* ---- one leaf item ---- */
+            if (mode == TS_LEAF) {
+                PS_WAVE_IT(PS_LEAF_IT, PS_LEAF_LANES);
+                const float4 *ip = reinterpret_cast<const float4 *>(sc.items + it_pos);
+                const float4 q0 = ip[0], q1 = ip[1], q2 = ip[2];
+                const int kind = __float_as_int(q2.w);
+                it_pos++;
+                if (COUNT) ri += 1;
+                bool ended = false;
+                if (kind == ITEM_TRI) {
+                    float t, b0, b1, b2;
+                    if (tri_hit_pre(ro, tr, tmax, f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), &t, &b0, &b1, &b2)) {
+                        tmax = t; hp = cp; hf = __float_as_int(q1.w); hb0 = b0; hb1 = b1; hit = true;
+                        ended = PT_ANY;
+                    }
+                } else {
+                    f3 o, dd;
+                    particle_object_ray(ro, rd, f3(q0.x, q0.y, q0.z), &o, &dd);
+                    float t;
+                    if (sphere_hit_t_obj(o, dd, q1.x, tmax, &t)) {
+                        tmax = t; hp = cp; hf = __float_as_int(q1.w); hb0 = 0; hb1 = 0; hit = true;
+                        ended = PT_ANY;
+                    }
+                }
+                if (ended) PT_FINISH();
+                else if (it_pos == it_end) PT_GEOM_NEXT();
+            }
+#ifdef PT_STATS
+            st_[PS_CYC_LEAF] += clock64() - c0_;
+#endif
+        } else {
+            /* ---- one step of the top level: the reference's own tree, step for step (primitive.cpp:374-431) ---- */
+            if (mode == TS_TOP || mode == TS_TOPLEAF) {
+                PS_WAVE_IT(PS_TOP_IT, PS_TOP_LANES);
+                if (mode == TS_TOPLEAF && leaf_pos == leaf_end) { /* leaf done: the popped node is tested in this same step */
+                    tnode = PT_POP();
+                    mode = TS_TOP;
+                }
+                if (mode == TS_TOP) {
+                    if (tnode == -1) PT_FINISH();
+                    else {
+                        const TopNode &nd = sc.top[tnode];
+                        float te;
+                        if (COUNT) rn += 1;
+                        if (slab_test(nd.bmin, nd.bmax, ro, inv, tmax, &te)) {
+                            if (nd.left < 0) {
+                                leaf_pos = nd.first;
+                                leaf_end = nd.first + nd.n;
+                                mode = TS_TOPLEAF;
+                            } else {
+                                const TopNode &l = sc.top[nd.left];
+                                const TopNode &r = sc.top[nd.right];
+                                float tl0, tr0;
+                                if (COUNT) rn += 2;
+                                bool visitL = slab_test(l.bmin, l.bmax, ro, inv, tmax, &tl0);
+                                bool visitR = slab_test(r.bmin, r.bmax, ro, inv, tmax, &tr0);
+                                if (visitR && visitL) {
+                                    int first, second;
+                                    if (tr0 < tl0) { first = nd.right; second = nd.left; }
+                                    else { first = nd.left; second = nd.right; }
+                                    PT_PUSH(second);
+                                    tnode = first;
+                                } else if (visitL) tnode = nd.left;
+                                else if (visitR) tnode = nd.right;
+                                else tnode = PT_POP();
+                            }
+                        } else tnode = PT_POP();
+                        if (mode == TS_TOP && tnode == -1) PT_FINISH(); /* nothing left: no extra round for the sentinel */
+                    }
+                } else {
+                    const int p = sc.order[leaf_pos++];
+                    const DPrim &pr = sc.prims[p];
+                    if (pr.type == SH_MESH || pr.type == SH_CLOUD) {
+                        cp = p;
+                        sp_base = sp;
+                        PT_ENTER(pr.root);
+                    } else {
+                        float t;
+                        int face;
+                        if (COUNT) ri += 1;
+                        if (shape_hit_t(sc, pr, ro, rd, tmax, &t, &face)) {
+                            tmax = t; hp = p; hf = face; hb0 = 0; hb1 = 0; hit = true;
+                            if (PT_ANY) PT_FINISH();
+                        }
+                    }
+                }
+            }
+#ifdef PT_STATS
+            st_[PS_CYC_TOP] += clock64() - c0_;
+#endif
+        }
+    }
+#ifdef PT_STATS
+    st_[PS_CYC_TOTAL] = clock64() - t_begin_;
+    if (lane == 0) {
+        const int ks[] = {PS_OUTER, PS_CYC_REFILL, PS_CYC_TOP, PS_CYC_IN, PS_CYC_LEAF, PS_CYC_TOTAL};
+        for (int k : ks) atomicAdd(&g_pt_stats[k], st_[k]);
+    }
+#endif
+#undef PT_FINISH
+#undef PT_ANY
+#undef PT_ENTER
+#undef PT_GEOM_NEXT
+}
+
+/* which schedule the kernels of rt_trace.hip use */
+#ifndef PT_SCHED
+#define PT_SCHED 0 /* r02 on config[1]: phases in sequence 190.5 ms per 32-spp pass, fullest-phase-first 193.2 */
+#endif
+template <class Source, bool COUNT>
+PD void persistent_trace_any(const DScene &sc, Source src, int *lds, unsigned *total_nodes, unsigned *total_items) {
+#if PT_SCHED
+    persistent_trace_sched<Source, COUNT>(sc, src, lds, total_nodes, total_items);
+#else
+    persistent_trace<Source, COUNT>(sc, src, lds, total_nodes, total_items);
+#endif
 }

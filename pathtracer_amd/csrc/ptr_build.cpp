@@ -249,10 +249,9 @@ struct Collapser {
         memset(&o, 0, sizeof(o));
         for (int i = 0; i < 4; i++) {
             if (i < n) {
-                o.mnx[i] = sl[i].box.mn[0]; o.mny[i] = sl[i].box.mn[1]; o.mnz[i] = sl[i].box.mn[2];
-                o.mxx[i] = sl[i].box.mx[0]; o.mxy[i] = sl[i].box.mx[1]; o.mxz[i] = sl[i].box.mx[2];
-                o.child[i] = refs[i];
-            } else o.child[i] = BVH_NO_CHILD;
+                for (int a = 0; a < 3; a++) { o.c[i].mn[a] = sl[i].box.mn[a]; o.c[i].mx[a] = sl[i].box.mx[a]; }
+                o.c[i].ref = refs[i];
+            } else o.c[i].ref = BVH_NO_CHILD;
         }
         return (int32_t)me;
     }

@@ -332,6 +332,13 @@ struct PtrContext {
     bool nee_one_launch = false; /* shadow + any-hit MIS rays of a bounce in one launch (PTR_NEE_ONE) */
     bool mis_any_hit = true; /* MIS rays as any-hit rays where the result cannot tell the difference (PTR_MIS_ANY=0: never) */
     bool scene_has_sss = false; /* some material carries a BSSRDF: k_shade<true> / k_finish<true> */
+    /* Which persistent tracer a launch uses.  One ray per lane (dev_trace.h) has the higher throughput once the GPU is full
+     * (r02, 14.4 M incoherent rays: 3.8 ms against 5.7 ms); four lanes per ray (dev_qtrace.h) has a quarter of the rays in
+     * flight, a third of the instructions per step and no scratch, and ends a small launch sooner (1.8 M rays: 1.04 ms
+     * against 1.41 ms).  PTR_TRACER=lane (default) | quad | auto: quad for launches expected to carry at most quad_below rays.  With six passes overlapping the
+     * small launches of one pass run beside the big ones of another, and auto gains nothing end to end. */
+    int tracer_mode = 0; /* 0 lane (default: r02 bench 1660 Mrays/s, auto 1653, quad 1062), 1 quad, 2 auto */
+    long long quad_below = 3000000;
     DCamera cam;
     int64_t bvh_bytes = 0;
     /* film */
@@ -447,14 +454,26 @@ static void prof_drain(PtrContext *ctx) {
 
 static inline unsigned nblocks(int n) { return (unsigned)((n + TPB - 1) / TPB); }
 static inline unsigned clampu(unsigned v, unsigned lo, unsigned hi) { return v < lo ? lo : (v > hi ? hi : v); }
+/* blocks of a persistent tracer launch over at most n rays: a 256-thread block holds 256 rays, or 64 with four lanes per ray */
+static inline unsigned trace_blocks(const struct PtrContext *ctx, long long n);
+static inline bool use_quad(const struct PtrContext *ctx, long long n);
 
+static inline bool use_quad(const PtrContext *ctx, long long n) { return ctx->tracer_mode == 1 || (ctx->tracer_mode == 2 && n <= ctx->quad_below); }
+static inline unsigned trace_blocks(const PtrContext *ctx, long long n) {
+    const long long per_block = use_quad(ctx, n) ? TPB / 4 : TPB;
+    long long b = (n + per_block - 1) / per_block;
+    return clampu((unsigned)(b > 0x7fffffff ? 0x7fffffff : b), 1, (unsigned)ctx->persist_blocks);
+}
 #define API_FETCH_SLOTS 256
 /* one launch of the persistent tracer; n_upper bounds the ray count for sizing the grid (the
  * count itself may be in device memory, io.n_ptr); io.counter must be zero when the kernel starts */
-static void launch_ptrace(PtrContext *ctx, hipStream_t s, const TraceIO &io, int n_upper, bool any, bool count, int family) {
-    unsigned blocks = clampu(nblocks(n_upper), 1, (unsigned)ctx->persist_blocks);
+static void launch_ptrace(PtrContext *ctx, hipStream_t s, const TraceIO &io, int n_upper, bool any, bool count, int family, long long n_est = -1) {
+    if (n_est < 0 || n_est > n_upper) n_est = n_upper; /* what picks the tracer: the expected ray count (n_upper only bounds it) */
+    const bool quad = use_quad(ctx, n_est);
+    unsigned blocks = trace_blocks(ctx, quad ? (n_est > 0 ? n_est : 1) : n_upper);
     ProfScope ps(ctx, s, family, (uint64_t)(io.n_ptr ? 0 : io.n));
-    rt_launch_ptrace(any, count, blocks, s, ctx->sc, io, ctx->ctrs);
+    if (quad) rt_launch_qtrace(any, count, blocks, s, ctx->sc, io, ctx->ctrs);
+    else rt_launch_ptrace(any, count, blocks, s, ctx->sc, io, ctx->ctrs);
 }
 static TraceIO soa_io(int n, const int *queue, long long plane, const float *o, const float *d, const float *tmax, int *prim, int *face,
                       float *t, float *b0, float *b1) {
@@ -571,6 +590,19 @@ static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int ste
         /* all staged bounces were still wide: stage one more next time */
         ctx->staged_bounces = k < l.staged_used ? k + 1 : l.staged_used + 1;
     }
+    /* expected ray counts per bounce {path segments, shadow rays, MIS rays}, from the same feedback: they pick the tracer
+     * of each launch (small launches go to the quad tracer); without feedback the grid-sizing bound stands in */
+    long long est[MAX_ITERS][3];
+    for (int k = 0; k < MAX_ITERS; k++) est[k][0] = est[k][1] = est[k][2] = -1;
+    if (l.staged_used > 0 && l.slots_used > 0 && hipEventQuery(l.film_done) == hipSuccess) {
+        const int *hc = l.counts_host;
+        const double scale = (double)slots / (double)l.slots_used;
+        for (int k = 0; k < l.staged_used && k < MAX_ITERS; k++) {
+            est[k][0] = k == 0 ? slots : (long long)(hc[4 * (k - 1)] * scale);
+            est[k][1] = (long long)(hc[4 * k + 2] * scale);
+            est[k][2] = (long long)(hc[4 * k + 3] * scale);
+        }
+    }
     const size_t cbytes = (size_t)LANE_COUNTER_INTS * sizeof(int);
     HIPCHK(hipMemsetAsync(l.counts, 0, cbytes, s));
     {
@@ -609,8 +641,9 @@ static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int ste
             const int n_upper = (more ? upper_at(k + 1) : 0) + 2 * upper_at(k);
             {
                 ProfScope ps(ctx, s, K_TRACE, 0);
-                rt_launch_ptrace3(ctx->count_traversal, clampu(nblocks(n_upper), 1, (unsigned)ctx->persist_blocks), s, ctx->sc, p,
-                                  shadow_io(l, l.queues[3], cnt + 2, nullptr), mis_io(l, l.queues[4], cnt + 3, nullptr), ctx->ctrs);
+                (use_quad(ctx, n_upper) ? rt_launch_qtrace3 : rt_launch_ptrace3)(ctx->count_traversal, trace_blocks(ctx, n_upper), s,
+                                                                         ctx->sc, p, shadow_io(l, l.queues[3], cnt + 2, nullptr),
+                                                                         mis_io(l, l.queues[4], cnt + 3, nullptr), ctx->ctrs);
             }
             enqueue_resolve(ctx, l, upper_at(k), k);
             q_cur = q_next;
@@ -620,7 +653,7 @@ static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int ste
         for (int k = 0; k < staged; k++) {
             int *q_next = l.queues[qi];
             const int *n_ptr = k == 0 ? nullptr : l.counts + 4 * (k - 1);
-            launch_ptrace(ctx, s, path_io(l, q_cur, n_ptr, slots, cursors + 3 * k), upper_at(k), false, ctx->count_traversal, K_TRACE);
+            launch_ptrace(ctx, s, path_io(l, q_cur, n_ptr, slots, cursors + 3 * k), upper_at(k), false, ctx->count_traversal, K_TRACE, est[k][0]);
             enqueue_shade(ctx, l, prm, n_ptr, slots, upper_at(k), q_cur, q_next, k);
             if (walks) enqueue_nee_walks(ctx, l, upper_at(k), k);
             else { /* a launch per ray kind */
@@ -632,11 +665,11 @@ static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int ste
                 mio.any_as_hit = mis_any ? 1 : 0;
                 if (mis_any && ctx->nee_one_launch) {
                     ProfScope ps(ctx, s, K_SHADOW, 0);
-                    rt_launch_ptrace2any(clampu(nblocks(2 * upper_at(k)), 1, (unsigned)ctx->persist_blocks), s, ctx->sc,
-                                         shadow_io(l, l.queues[3], cnt + 2, cursors + 3 * k + 1), mio);
+                    (use_quad(ctx, 2ll * upper_at(k)) ? rt_launch_qtrace2any : rt_launch_ptrace2any)(trace_blocks(ctx, 2ll * upper_at(k)), s,
+                                                                                     ctx->sc, shadow_io(l, l.queues[3], cnt + 2, cursors + 3 * k + 1), mio);
                 } else {
-                launch_ptrace(ctx, s, shadow_io(l, l.queues[3], cnt + 2, cursors + 3 * k + 1), upper_at(k), true, false, K_SHADOW);
-                launch_ptrace(ctx, s, mio, upper_at(k), mis_any, ctx->count_traversal, mis_any ? K_MIS_ANY : K_MIS);
+                launch_ptrace(ctx, s, shadow_io(l, l.queues[3], cnt + 2, cursors + 3 * k + 1), upper_at(k), true, false, K_SHADOW, est[k][1]);
+                launch_ptrace(ctx, s, mio, upper_at(k), mis_any, ctx->count_traversal, mis_any ? K_MIS_ANY : K_MIS, est[k][2]);
                 }
                 enqueue_resolve(ctx, l, upper_at(k), k);
             }
@@ -713,6 +746,8 @@ int ptr_create(int device, PtrContext **out) {
         if (v > 0) { ctx->staged_bounces = v; ctx->staged_fixed = true; }
     }
     if (const char *e = getenv("PTR_MERGE")) ctx->merge_traces = atoi(e) != 0; /* tuning experiments */
+    if (const char *e = getenv("PTR_TRACER")) ctx->tracer_mode = !strcmp(e, "quad") ? 1 : (!strcmp(e, "auto") ? 2 : 0);
+    if (const char *e = getenv("PTR_QUAD_BELOW")) { long long v = atoll(e); if (v >= 0) ctx->quad_below = v; }
     if (const char *e = getenv("PTR_NEE_ONE")) ctx->nee_one_launch = atoi(e) != 0;
     if (const char *e = getenv("PTR_STAGE_DIV")) { int v = atoi(e); if (v > 0) ctx->stage_div = v; }
     if (const char *e = getenv("PTR_MIS_ANY")) ctx->mis_any_hit = atoi(e) != 0;

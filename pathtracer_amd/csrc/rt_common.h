@@ -144,3 +144,8 @@ void rt_launch_ptrace2any(unsigned blocks, hipStream_t s, const DScene &sc, cons
 void rt_launch_ptrace3(bool count, unsigned blocks, hipStream_t s, const DScene &sc, const TraceIO &path, const TraceIO &shadow, const TraceIO &mis,
                        unsigned long long *ctrs);
 void rt_launch_ptrace(bool any, bool count, unsigned blocks, hipStream_t s, const DScene &sc, const TraceIO &io, unsigned long long *ctrs); /* rt_trace.hip */
+/* the same three launches with four lanes per ray (dev_qtrace.h), rt_qtrace.hip */
+void rt_launch_qtrace2any(unsigned blocks, hipStream_t s, const DScene &sc, const TraceIO &a, const TraceIO &b);
+void rt_launch_qtrace3(bool count, unsigned blocks, hipStream_t s, const DScene &sc, const TraceIO &path, const TraceIO &shadow, const TraceIO &mis,
+                       unsigned long long *ctrs);
+void rt_launch_qtrace(bool any, bool count, unsigned blocks, hipStream_t s, const DScene &sc, const TraceIO &io, unsigned long long *ctrs);

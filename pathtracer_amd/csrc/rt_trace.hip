@@ -11,7 +11,7 @@ __global__ void __launch_bounds__(TRACE_TPB) __attribute__((amdgpu_waves_per_eu(
     unsigned tn = 0, ti = 0;
     OneSource<ANY> src;
     src.io = io;
-    persistent_trace<OneSource<ANY>, COUNT>(sc, src, &s_stack[threadIdx.x], &tn, &ti);
+    persistent_trace_any<OneSource<ANY>, COUNT>(sc, src, &s_stack[threadIdx.x], &tn, &ti);
     if (COUNT) {
         ctr_flush(ctrs, C_NODES, tn);
         ctr_flush(ctrs, C_PRIMS, ti);
@@ -28,7 +28,7 @@ k_ptrace3(DScene sc, TraceIO path, TraceIO shadow, TraceIO mis, unsigned long lo
     src.path = path;
     src.shadow = shadow;
     src.mis = mis;
-    persistent_trace<ThreeSources, COUNT>(sc, src, &s_stack[threadIdx.x], &tn, &ti);
+    persistent_trace_any<ThreeSources, COUNT>(sc, src, &s_stack[threadIdx.x], &tn, &ti);
     if (COUNT) {
         ctr_flush(ctrs, C_NODES, tn);
         ctr_flush(ctrs, C_PRIMS, ti);
@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(TRACE_TPB) __attribute__((amdgpu_waves_per_eu(
     TwoAny src;
     src.a = a;
     src.b = b;
-    persistent_trace<TwoAny, false>(sc, src, &s_stack[threadIdx.x], &tn, &ti);
+    persistent_trace_any<TwoAny, false>(sc, src, &s_stack[threadIdx.x], &tn, &ti);
 }
 void rt_launch_ptrace2any(unsigned blocks, hipStream_t s, const DScene &sc, const TraceIO &a, const TraceIO &b) {
     hipLaunchKernelGGL(k_ptrace2any, dim3(blocks), dim3(TRACE_TPB), 0, s, sc, a, b);
@@ -58,3 +58,16 @@ void rt_launch_ptrace(bool any, bool count, unsigned blocks, hipStream_t s, cons
     else if (count) hipLaunchKernelGGL((k_ptrace<false, true>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, io, ctrs);
     else hipLaunchKernelGGL((k_ptrace<false, false>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, io, ctrs);
 }
+
+#ifdef PT_STATS
+/* diagnostic build only (tools/gpu_tracestats.py): read and clear the phase statistics of dev_trace.h */
+extern "C" int ptr_debug_trace_stats(unsigned long long *out, int n) {
+    unsigned long long tmp[PS_N] = {};
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(tmp, HIP_SYMBOL(g_pt_stats), sizeof(tmp)) != hipSuccess) return 1;
+    for (int i = 0; i < n && i < PS_N; i++) out[i] = tmp[i];
+    unsigned long long zero[PS_N] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_pt_stats), zero, sizeof(zero)) != hipSuccess) return 1;
+    return 0;
+}
+#endif
