@@ -249,8 +249,10 @@ int ptr_film_init(PtrContext *ctx, int width, int height, uint64_t seed);
  * renders only sample indices s with s % stride == offset.  Default (0,1). */
 int ptr_film_shard(PtrContext *ctx, int sample_offset, int sample_stride);
 /* Replaces Render<<<blocks,threads>>>(image, scene, camera, ns) (main.cpp:421-457,1139):
- * ns more samples for every pixel with integrator PTR_LI_*.  Asynchronous on the
- * context's stream. */
+ * ns more samples for every pixel with integrator PTR_LI_*.  Asynchronous, and ordered with the
+ * context's stream (ptr_set_stream; default: the null stream) on both sides: the passes run on internal
+ * streams that first wait for everything queued on the context's stream before this call, and work
+ * queued on the context's stream after this call waits for the passes. */
 int ptr_render(PtrContext *ctx, int ns, int integrator);
 /* Replaces cudaDeviceAssert() after a launch (main.cpp:1140). */
 int ptr_sync(PtrContext *ctx);

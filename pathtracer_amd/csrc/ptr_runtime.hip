@@ -348,6 +348,9 @@ struct PtrContext {
     double *acc = nullptr;
     long long *samples = nullptr;
     int sample_cursor = 0, shard_offset = 0, shard_stride = 1;
+    unsigned char *rgb8 = nullptr; /* 3 * npix bytes: where ptr_film_rgb8 resolves the film before the copy to the host */
+    hipEvent_t entry = nullptr;    /* recorded on the caller's stream when ptr_render is entered: the lanes wait for it */
+    bool debug_sync = false;       /* PTR_DEBUG_SYNC=1: wait and check for errors after every stage of a pass */
     /* pipeline */
     Lane lanes[N_LANES];
     int next_lane = 0, last_film_lane = -1;
@@ -398,10 +401,11 @@ static void free_scene(PtrContext *ctx) {
     ctx->has_scene = false;
 }
 static void free_film(PtrContext *ctx) {
-    void *film[] = {ctx->we, ctx->acc, ctx->samples};
+    void *film[] = {ctx->we, ctx->acc, ctx->samples, ctx->rgb8};
     for (void *p : film)
         if (p) (void)hipFree(p);
-    ctx->we = nullptr; ctx->acc = nullptr; ctx->samples = nullptr;
+    ctx->we = nullptr; ctx->acc = nullptr; ctx->samples = nullptr; ctx->rgb8 = nullptr;
+    if (!ctx->staged_fixed) ctx->staged_bounces = 6; /* the feedback below belongs to the buffers that go away */
     for (Lane &l : ctx->lanes) {
         void *ptrs[] = {l.pipe.ro, l.pipe.rd, l.pipe.hprim, l.pipe.hface, l.pipe.ht, l.pipe.paths, l.pipe.nee,
                         l.queues[0], l.queues[1], l.queues[2], l.queues[3], l.queues[4], l.queues[5], l.counts};
@@ -412,6 +416,8 @@ static void free_film(PtrContext *ctx) {
         for (int q = 0; q < 6; q++) l.queues[q] = nullptr;
         l.counts = nullptr;
         l.counts_host = nullptr;
+        l.staged_used = 0;
+        l.slots_used = 0;
     }
     ctx->has_film = false;
 }
@@ -569,6 +575,15 @@ static void enqueue_resolve(PtrContext *ctx, Lane &l, int n_upper, int cslot) {
                        (const int *)l.queues[2], ctx->ctrs);
 }
 
+/* PTR_DEBUG_SYNC=1: wait for the lane after a stage and report the stage a failure belongs to (a pass queues ~10 launches
+ * per bounce and otherwise looks at the error status once, at its end) */
+#define STAGE_CHECK(what)                                                                                         \
+    do {                                                                                                          \
+        hipError_t le_ = hipGetLastError();                                                                       \
+        if (le_ == hipSuccess && ctx->debug_sync) le_ = hipStreamSynchronize(s);                                  \
+        if (le_ != hipSuccess) return set_err(PTR_ERR_HIP, std::string("pass stage '") + (what) + "': " + hipGetErrorString(le_)); \
+    } while (0)
+
 /* one pass on a lane: nb samples (first, first+step, ...) of every pixel */
 static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int step, int nb, int integrator) {
     PassParams prm;
@@ -603,6 +618,7 @@ static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int ste
             est[k][2] = (long long)(hc[4 * k + 3] * scale);
         }
     }
+    HIPCHK(hipStreamWaitEvent(s, ctx->entry, 0));
     const size_t cbytes = (size_t)LANE_COUNTER_INTS * sizeof(int);
     HIPCHK(hipMemsetAsync(l.counts, 0, cbytes, s));
     {
@@ -610,6 +626,7 @@ static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int ste
         hipLaunchKernelGGL(k_raygen, dim3(nblocks(slots)), dim3(TPB), 0, s, ctx->sc, ctx->cam, l.pipe, prm, slots);
     }
     ctx->camera_rays += (uint64_t)slots;
+    STAGE_CHECK("raygen");
 
     /* Staged bounces while the pass is wide, then one launch that runs the survivors to their end
      * (no bound on path length is needed: media boundaries without material do not count as
@@ -646,6 +663,7 @@ static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int ste
                                                                          mis_io(l, l.queues[4], cnt + 3, nullptr), ctx->ctrs);
             }
             enqueue_resolve(ctx, l, upper_at(k), k);
+            STAGE_CHECK("bounce (merged traces)");
             q_cur = q_next;
             qi ^= 1;
         }
@@ -654,7 +672,9 @@ static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int ste
             int *q_next = l.queues[qi];
             const int *n_ptr = k == 0 ? nullptr : l.counts + 4 * (k - 1);
             launch_ptrace(ctx, s, path_io(l, q_cur, n_ptr, slots, cursors + 3 * k), upper_at(k), false, ctx->count_traversal, K_TRACE, est[k][0]);
+            STAGE_CHECK("trace");
             enqueue_shade(ctx, l, prm, n_ptr, slots, upper_at(k), q_cur, q_next, k);
+            STAGE_CHECK("miss / shade / route");
             if (walks) enqueue_nee_walks(ctx, l, upper_at(k), k);
             else { /* a launch per ray kind */
                 int *cnt = l.counts + 4 * k;
@@ -673,6 +693,7 @@ static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int ste
                 }
                 enqueue_resolve(ctx, l, upper_at(k), k);
             }
+            STAGE_CHECK("direct light");
             q_cur = q_next;
             qi ^= 1;
         }
@@ -685,6 +706,7 @@ static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int ste
         const unsigned blocks = clampu(nblocks(upper), 32, 2048);
         if (ctx->scene_has_sss) rt_launch_finish_sss(blocks, s, a);
         else rt_launch_finish(blocks, s, a);
+        STAGE_CHECK("finish");
     }
     l.staged_used = staged;
     l.slots_used = slots;
@@ -729,6 +751,7 @@ int ptr_create(int device, PtrContext **out) {
     bool ok = hipMalloc((void **)&ctx->ctrs, CTR_REPLICAS * CTR_STRIDE * sizeof(unsigned long long)) == hipSuccess &&
               hipMemset(ctx->ctrs, 0, CTR_REPLICAS * CTR_STRIDE * sizeof(unsigned long long)) == hipSuccess &&
               hipMalloc((void **)&ctx->api_fetch, API_FETCH_SLOTS * sizeof(int)) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&ctx->entry, hipEventDisableTiming) == hipSuccess;
     for (Lane &l : ctx->lanes) {
         memset(&l.pipe, 0, sizeof(l.pipe));
         ok = ok && hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) == hipSuccess &&
@@ -745,6 +768,7 @@ int ptr_create(int device, PtrContext **out) {
         int v = atoi(e);
         if (v > 0) { ctx->staged_bounces = v; ctx->staged_fixed = true; }
     }
+    if (const char *e = getenv("PTR_DEBUG_SYNC")) ctx->debug_sync = atoi(e) != 0;
     if (const char *e = getenv("PTR_MERGE")) ctx->merge_traces = atoi(e) != 0; /* tuning experiments */
     if (const char *e = getenv("PTR_TRACER")) ctx->tracer_mode = !strcmp(e, "quad") ? 1 : (!strcmp(e, "auto") ? 2 : 0);
     if (const char *e = getenv("PTR_QUAD_BELOW")) { long long v = atoll(e); if (v >= 0) ctx->quad_below = v; }
@@ -776,6 +800,7 @@ int ptr_destroy(PtrContext *ctx) {
         if (l.joined) (void)hipEventDestroy(l.joined);
         if (l.stream) (void)hipStreamDestroy(l.stream);
     }
+    if (ctx->entry) (void)hipEventDestroy(ctx->entry);
     if (ctx->ctrs) (void)hipFree(ctx->ctrs);
     if (ctx->api_fetch) (void)hipFree(ctx->api_fetch);
     delete ctx;
@@ -891,6 +916,34 @@ int ptr_camera_set(PtrContext *ctx, const PtrCamera *cam) {
     return PTR_OK;
 }
 
+/* bytes of pass buffers per path slot and lane: ray 24 + hit 12 + PathRec + NeeRec + six queues */
+static size_t lane_bytes_per_slot() { return 24 + 12 + sizeof(PathRec) + sizeof(NeeRec) + 6 * sizeof(int); }
+/* the pass buffers of every lane for nb samples per pass; on failure everything allocated so far is freed */
+static hipError_t alloc_lanes(PtrContext *ctx, int npix, int nb) {
+    const size_t cap = (size_t)npix * nb;
+    const size_t cap_tiles = ((cap + ((size_t)1 << PLANE_TILE_SHIFT) - 1) >> PLANE_TILE_SHIFT) << PLANE_TILE_SHIFT; /* whole tiles */
+    hipError_t e = hipSuccess;
+#define TRY(expr) do { if (e == hipSuccess) e = (expr); } while (0)
+    for (Lane &l : ctx->lanes) {
+        TRY(hipMalloc((void **)&l.pipe.ro, 3 * sizeof(float) * cap));
+        TRY(hipMalloc((void **)&l.pipe.rd, 3 * sizeof(float) * cap));
+        TRY(hipMalloc((void **)&l.pipe.hprim, sizeof(int) * cap));
+        TRY(hipMalloc((void **)&l.pipe.hface, sizeof(int) * cap));
+        TRY(hipMalloc((void **)&l.pipe.ht, sizeof(float) * cap));
+        TRY(hipMalloc((void **)&l.pipe.paths, sizeof(PathRec) * cap_tiles)); /* PATH_WORDS tiled planes */
+        TRY(hipMalloc((void **)&l.pipe.nee, sizeof(NeeRec) * cap_tiles));     /* NEE_WORDS tiled planes */
+        for (int q = 0; q < 6; q++) TRY(hipMalloc((void **)&l.queues[q], sizeof(int) * cap));
+        TRY(hipMalloc((void **)&l.counts, LANE_COUNTER_INTS * sizeof(int)));
+        TRY(hipHostMalloc((void **)&l.counts_host, 4 * MAX_ITERS * sizeof(int), hipHostMallocDefault));
+        if (e == hipSuccess) {
+            memset(l.counts_host, 0, 4 * MAX_ITERS * sizeof(int));
+            l.pipe.cap = (int)cap;
+        }
+    }
+#undef TRY
+    return e;
+}
+
 int ptr_film_init(PtrContext *ctx, int width, int height, uint64_t seed) {
     int rc = ctx_use(ctx);
     if (rc) return rc;
@@ -901,36 +954,48 @@ int ptr_film_init(PtrContext *ctx, int width, int height, uint64_t seed) {
         free_film(ctx);
         /* samples per pass: launches last as long as their longest ray (~2 ms on config[1]) while
          * the marginal cost is ~0.25 ns per ray, so a pass should carry tens of millions of path slots
-         * (config[1], end of round 1: 32 M -> 1578, 64 M -> 1658, 128 M -> 1694 Mrays/s; ~300 B of HBM per slot and lane,
-         * six lanes: 64 M slots = 117 GB of the 288 GB) */
+         * (config[1], end of round 1: 32 M -> 1578, 64 M -> 1658, 128 M -> 1694 Mrays/s; 300 B of HBM per slot and lane,
+         * six lanes: 64 M slots = 117 GB of the 288 GB).  That is the target, not a requirement: the pass shrinks to what
+         * the device has free (PTR_PASS_SLOTS sets another target), down to one sample of every pixel per pass. */
         long long target = 1ll << 26;
-        if (const char *e = getenv("PTR_PASS_SLOTS")) { /* tuning experiments */
+        if (const char *e = getenv("PTR_PASS_SLOTS")) {
             long long v = atoll(e);
             if (v > 0) target = v;
         }
         int nb = (int)(target / npix);
         if (nb < 1) nb = 1;
         if (nb > 64) nb = 64;
-        size_t cap = (size_t)npix * nb;
-        if (cap > (size_t)1 << 29) return set_err(PTR_ERR_LIMIT, "film too large for one pass"); /* 3 * cap is indexed with an int */
-        ctx->nb_max = nb;
-        HIPCHK(hipMalloc((void **)&ctx->we, 3 * sizeof(float) * npix));
-        HIPCHK(hipMalloc((void **)&ctx->acc, sizeof(double) * npix));
-        HIPCHK(hipMalloc((void **)&ctx->samples, sizeof(long long) * npix));
-        for (Lane &l : ctx->lanes) {
-            const size_t cap_tiles = ((cap + ((size_t)1 << PLANE_TILE_SHIFT) - 1) >> PLANE_TILE_SHIFT) << PLANE_TILE_SHIFT; /* whole tiles */
-            HIPCHK(hipMalloc((void **)&l.pipe.ro, 3 * sizeof(float) * cap));
-            HIPCHK(hipMalloc((void **)&l.pipe.rd, 3 * sizeof(float) * cap));
-            HIPCHK(hipMalloc((void **)&l.pipe.hprim, sizeof(int) * cap));
-            HIPCHK(hipMalloc((void **)&l.pipe.hface, sizeof(int) * cap));
-            HIPCHK(hipMalloc((void **)&l.pipe.ht, sizeof(float) * cap));
-            HIPCHK(hipMalloc((void **)&l.pipe.paths, sizeof(PathRec) * cap_tiles)); /* PATH_WORDS tiled planes */
-            HIPCHK(hipMalloc((void **)&l.pipe.nee, sizeof(NeeRec) * cap_tiles));     /* NEE_WORDS tiled planes */
-            for (int q = 0; q < 6; q++) HIPCHK(hipMalloc((void **)&l.queues[q], sizeof(int) * cap));
-            HIPCHK(hipMalloc((void **)&l.counts, LANE_COUNTER_INTS * sizeof(int)));
-            HIPCHK(hipHostMalloc((void **)&l.counts_host, 4 * MAX_ITERS * sizeof(int), hipHostMallocDefault));
-            l.pipe.cap = (int)cap;
+        if ((size_t)npix * nb > (size_t)1 << 29) nb = (int)(((size_t)1 << 29) / npix); /* 3 * cap is indexed with an int */
+        if (nb < 1) return set_err(PTR_ERR_LIMIT, "film too large for one pass");
+        hipError_t e = hipMalloc((void **)&ctx->we, 3 * sizeof(float) * npix);
+        if (e == hipSuccess) e = hipMalloc((void **)&ctx->acc, sizeof(double) * npix);
+        if (e == hipSuccess) e = hipMalloc((void **)&ctx->samples, sizeof(long long) * npix);
+        if (e == hipSuccess) e = hipMalloc((void **)&ctx->rgb8, 3 * (size_t)npix);
+        if (e != hipSuccess) {
+            free_film(ctx);
+            return set_err(PTR_ERR_HIP, std::string("film accumulators: ") + hipGetErrorString(e));
         }
+        /* start from what fits in 90 % of the free memory, then halve on failure */
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const double budget = 0.9 * (double)free_b;
+            while (nb > 1 && (double)npix * nb * (double)lane_bytes_per_slot() * N_LANES > budget) nb = (nb + 1) / 2;
+        }
+        for (;;) {
+            e = alloc_lanes(ctx, npix, nb);
+            if (e == hipSuccess) break;
+            (void)hipGetLastError(); /* clear the sticky out-of-memory status */
+            void *keep[] = {ctx->we, ctx->acc, ctx->samples, ctx->rgb8};
+            ctx->we = nullptr; ctx->acc = nullptr; ctx->samples = nullptr; ctx->rgb8 = nullptr;
+            free_film(ctx); /* the half-built lanes */
+            ctx->we = (float *)keep[0]; ctx->acc = (double *)keep[1]; ctx->samples = (long long *)keep[2]; ctx->rgb8 = (unsigned char *)keep[3];
+            if (nb == 1 || e != hipErrorOutOfMemory) {
+                free_film(ctx);
+                return set_err(PTR_ERR_HIP, std::string("pass buffers (") + std::to_string((size_t)npix * nb) + " slots): " + hipGetErrorString(e));
+            }
+            nb = nb / 2;
+        }
+        ctx->nb_max = nb;
     }
     ctx->width = width;
     ctx->height = height;
@@ -961,6 +1026,10 @@ int ptr_render(PtrContext *ctx, int ns, int integrator) {
         return set_err(PTR_ERR_STATE, "ptr_render needs ptr_scene_upload, ptr_camera_set and ptr_film_init first");
     if (ns < 0) return set_err(PTR_ERR_INVALID, "negative sample count");
     if (integrator < PTR_LI_DIRECT || integrator > PTR_LI_VOLPATH) return set_err(PTR_ERR_INVALID, "unknown integrator");
+    /* work the caller queued on its stream before this call (a film restore, an all-reduce of the accumulators, a
+     * kernel of its own on ptr_film_device_ptrs) happens before anything a pass does: the lanes are separate
+     * non-blocking streams, so they are made to wait for the caller's stream here */
+    HIPCHK(hipEventRecord(ctx->entry, ctx->stream));
     int begin = ctx->sample_cursor, end = begin + ns;
     ctx->sample_cursor = end;
     /* first sample index >= begin owned by this shard */
@@ -1029,14 +1098,12 @@ int ptr_film_rgb8(PtrContext *ctx, float exposure, int algorithm, unsigned char 
     if (!rgb) return set_err(PTR_ERR_INVALID, "null output");
     if (algorithm < PTR_TONEMAP_REINHARD || algorithm > PTR_TONEMAP_NAUGHTYDOG) return set_err(PTR_ERR_INVALID, "unknown tone mapping algorithm");
     if ((rc = sync_all(ctx))) return rc;
-    unsigned char *d = nullptr;
-    HIPCHK(hipMalloc((void **)&d, 3 * (size_t)ctx->npix));
+    unsigned char *d = ctx->rgb8; /* allocated with the film */
     hipLaunchKernelGGL(k_tonemap, dim3(nblocks(ctx->npix)), dim3(TPB), 0, ctx->stream, (const float *)ctx->we, (const double *)ctx->acc, ctx->npix, exposure,
                        algorithm, d);
-    hipError_t e = hipMemcpyAsync(rgb, d, 3 * (size_t)ctx->npix, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d);
-    if (e != hipSuccess) return set_err(PTR_ERR_HIP, hipGetErrorString(e));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(rgb, d, 3 * (size_t)ctx->npix, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     return PTR_OK;
 }
 

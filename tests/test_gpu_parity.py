@@ -287,5 +287,67 @@ def test_caller_stream(scenes):
         r.sync()
         assert float(early) == float(we_t.double().sum()) and float(early) > 0
         assert int(smp_t.min()) == 6
+
+        # the other direction: what the caller queued on its stream BEFORE ptr_render (here a slow kernel chain that ends by
+        # writing the accumulators, as an all-reduce or a film restore would) is in the film the passes add to
+        r.film_init(W, H, SEED)
+        r.render(6, pa.LI_PATH)
+        r.sync()
+        base_we, base_acc = we_t.clone(), acc_t.clone()
+        r.film_init(W, H, SEED)
+        big = torch.randn(4096, 4096, device=dev)
+        with torch.cuda.stream(s):
+            for _ in range(6):
+                big = big @ big * 1e-3  # keeps the stream busy for a while
+            we_t.fill_(2.0)
+            acc_t.fill_(3.0)
+            r.render(6, pa.LI_PATH)  # no host sync between the fills and the render
+        s.synchronize()
+        r.sync()
+        assert torch.allclose(we_t, base_we + 2.0, rtol=1e-6, atol=1e-6)
+        assert torch.allclose(acc_t, base_acc + 3.0, rtol=1e-12, atol=1e-9)
     finally:
         r.set_stream(0)
+
+
+def test_film_init_shrinks_and_recovers(scenes):
+    """ptr_film_init sizes its pass buffers to what the device has: a target far beyond the memory (PTR_PASS_SLOTS) ends
+    in a smaller pass, not in an error, the render is the same image, and a film that cannot be allocated at all leaves
+    nothing behind (a normal film can be made right after)."""
+    import os
+    import torch
+    sc, o, r = scenes("cornell")
+    r.film_init(W, H, SEED)
+    r.render(4, pa.LI_PATHSAMPLED)
+    r.sync()
+    want = r.film()
+    free0 = torch.cuda.mem_get_info()[0]
+    # 4096 x 4096 pixels x 64 samples would be 2^30 slots x 300 B x 6 lanes = 1.9 TB: must shrink (to at most 2^29 slots, then to what is free)
+    old = os.environ.get("PTR_PASS_SLOTS")
+    os.environ["PTR_PASS_SLOTS"] = str(1 << 40)
+    try:
+        r.film_init(4096, 4096, SEED)
+        free1 = torch.cuda.mem_get_info()[0]
+        assert free1 < free0  # something was allocated, and within the device
+        r.film_init(W, H, SEED)  # back to the small film: the big buffers are released
+        r.render(4, pa.LI_PATHSAMPLED)
+        r.sync()
+        got = r.film()
+        for a, b in zip(want, got):
+            assert np.array_equal(a, b)
+        # a film whose pass buffers cannot exist even at one sample per pass (2^28 pixels x 300 B x 6 lanes = 483 GB):
+        # an error, and nothing stays allocated
+        with pytest.raises(pa.capi.PtrError):
+            r.film_init(16384, 16384, SEED)
+        assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)
+    finally:
+        if old is None:
+            os.environ.pop("PTR_PASS_SLOTS", None)
+        else:
+            os.environ["PTR_PASS_SLOTS"] = old
+    r.film_init(W, H, SEED)
+    r.render(4, pa.LI_PATHSAMPLED)
+    r.sync()
+    got = r.film()
+    for a, b in zip(want, got):
+        assert np.array_equal(a, b)
