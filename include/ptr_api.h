@@ -295,6 +295,19 @@ int ptr_generate_rays(PtrContext *ctx, int sample, float *d_o, float *d_d, float
 int ptr_trace_closest(PtrContext *ctx, int n, const float *d_o, const float *d_d,
                       const float *d_tmax, int32_t *d_prim, int32_t *d_face, float *d_t,
                       float *d_b0, float *d_b1);
+/* ptr_trace_closest for callers that cannot allocate device memory: code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  No counterpart in the reference.  Same arguments, same results bit for
+ * bit; it calls no hipMalloc / hipFree (nor any allocating library routine) and does not synchronise: one 256-byte
+ * memset and one kernel launch on the context's stream.  The tracer's ray-fetch cursor - the only device memory the
+ * call needs beyond its inputs and outputs - lives in a 256-byte `static __device__` array of the library (one copy per
+ * GPU, held until the process ends) instead of the hipMalloc'ed ring ptr_trace_closest uses.  Limits: at most
+ * PTR_TRACE_NOALLOC_MAX_RAYS rays per call (the cursor is a 32-bit int and runs past n by one grab per resident
+ * wavefront; more rays: PTR_ERR_LIMIT, nothing is launched); every call on a GPU shares that GPU's array, so two
+ * calls that overlap on one GPU (different contexts or streams) race - run them one after the other on one stream. */
+#define PTR_TRACE_NOALLOC_MAX_RAYS (1 << 30)
+int ptr_trace_closest_noalloc(PtrContext *ctx, int n, const float *d_o, const float *d_d,
+                              const float *d_tmax, int32_t *d_prim, int32_t *d_face, float *d_t,
+                              float *d_b0, float *d_b1);
 /* VisibilityTester::Unoccluded (light.cpp:5-8): d_occluded[n] = 1 if anything is hit. */
 int ptr_trace_occluded(PtrContext *ctx, int n, const float *d_o, const float *d_d,
                        const float *d_tmax, int32_t *d_occluded);

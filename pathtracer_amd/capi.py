@@ -114,6 +114,7 @@ HIP_SIGNATURES = {
     "ptr_counters_reset": (C.c_int, [CTX]),
     "ptr_generate_rays": (C.c_int, [CTX, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ptr_trace_closest": (C.c_int, [CTX, C.c_int] + [C.c_void_p] * 8),
+    "ptr_trace_closest_noalloc": (C.c_int, [CTX, C.c_int] + [C.c_void_p] * 8),
     "ptr_trace_occluded": (C.c_int, [CTX, C.c_int] + [C.c_void_p] * 4),
     "ptr_profile_enable": (C.c_int, [CTX, C.c_int]),
     "ptr_profile_reset": (C.c_int, [CTX]),

@@ -278,6 +278,20 @@ __global__ void __launch_bounds__(TPB) k_film(Pipe pp, int npix, int nbatch, flo
 }
 
 /* ------------------------------------------------------------------------------------------
+ * scratch of the entry point that allocates nothing (ptr_trace_closest_noalloc, include/ptr_api.h)
+ *
+ * The persistent tracer hands out rays through a fetch cursor in device memory.  ptr_trace_closest takes its
+ * cursor from a ring the context allocated with hipMalloc; the no-allocation variant keeps it here, in the code
+ * object itself.  Every GPU the library runs on holds its own copy of this array until the process ends.  In host
+ * code `scratch` is only a handle: the device address is asked for once per device (ptr_create, with that device
+ * current) and kept in g_scratch_ptr[device]; kernels, memsets and copies only ever see that address.
+ * ---------------------------------------------------------------------------------------- */
+#define PTR_SCRATCH_INTS 64 /* 256 B: word 0 = ray-fetch cursor of the call in flight, the rest reserved */
+static __device__ __align__(256) int scratch[PTR_SCRATCH_INTS];
+#define PTR_MAX_DEVICES 64
+static int *g_scratch_ptr[PTR_MAX_DEVICES]; /* per device: where that GPU's copy of scratch[] lives */
+
+/* ------------------------------------------------------------------------------------------
  * host runtime
  * ---------------------------------------------------------------------------------------- */
 static thread_local std::string g_err;
@@ -359,6 +373,7 @@ struct PtrContext {
     int stage_div = 1024; /* a bounce is staged while more than slots / stage_div paths are alive (PTR_STAGE_DIV) */
     int spread = 1; /* a ptr_render call deals its samples to this many passes (lanes) */
     int *api_fetch = nullptr; /* ray-fetch cursors of the stand-alone trace entry points (rotating) */
+    int *static_scratch = nullptr; /* this device's copy of scratch[] (ptr_trace_closest_noalloc) */
     int api_fetch_next = 0;
     int persist_blocks = 1024;
     int nb_max = 1;
@@ -741,8 +756,15 @@ int ptr_create(int device, PtrContext **out) {
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
     if (prop.warpSize != 64) return set_err(PTR_ERR_HIP, "device wavefront size is not 64 (built for gfx950)");
+    if (device >= PTR_MAX_DEVICES) return set_err(PTR_ERR_LIMIT, "device index beyond PTR_MAX_DEVICES");
+    if (!g_scratch_ptr[device]) { /* once per device, with that device current (hipSetDevice above) */
+        int *p = nullptr;
+        HIPCHK(hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch)));
+        g_scratch_ptr[device] = p;
+    }
     PtrContext *ctx = new PtrContext();
     ctx->device = device;
+    ctx->static_scratch = g_scratch_ptr[device];
     memset(&ctx->sc, 0, sizeof(ctx->sc));
     memset(&ctx->cam, 0, sizeof(ctx->cam));
     memset(ctx->prof_ms, 0, sizeof(ctx->prof_ms));
@@ -1168,6 +1190,29 @@ int ptr_trace_closest(PtrContext *ctx, int n, const float *d_o, const float *d_d
     if (n < 0 || (n > 0 && (!d_o || !d_d || !d_prim || !d_face || !d_t))) return set_err(PTR_ERR_INVALID, "bad ray batch");
     if (n == 0) return PTR_OK;
     return api_trace(ctx, soa_io(n, nullptr, n, d_o, d_d, d_tmax, d_prim, d_face, d_t, d_b0, d_b1), false);
+}
+
+int ptr_trace_closest_noalloc(PtrContext *ctx, int n, const float *d_o, const float *d_d, const float *d_tmax, int32_t *d_prim, int32_t *d_face,
+                              float *d_t, float *d_b0, float *d_b1) {
+    int rc = ctx_use(ctx);
+    if (rc) return rc;
+    if (!ctx->has_scene) return set_err(PTR_ERR_STATE, "no scene uploaded");
+    if (n > PTR_TRACE_NOALLOC_MAX_RAYS) return set_err(PTR_ERR_LIMIT, "ptr_trace_closest_noalloc: more than PTR_TRACE_NOALLOC_MAX_RAYS rays in one call");
+    if (n < 0 || (n > 0 && (!d_o || !d_d || !d_prim || !d_face || !d_t))) return set_err(PTR_ERR_INVALID, "bad ray batch");
+    if (n == 0) return PTR_OK;
+    int *cursor = ctx->static_scratch; /* the device address of scratch[] on this GPU, never the symbol */
+    if (!cursor) return set_err(PTR_ERR_STATE, "static scratch not resolved for this device");
+    TraceIO io = soa_io(n, nullptr, n, d_o, d_d, d_tmax, d_prim, d_face, d_t, d_b0, d_b1);
+    io.counter = cursor;
+    /* the array keeps what the last call left in it: the cursor must start at zero */
+    HIPCHK(hipMemsetAsync(cursor, 0, PTR_SCRATCH_INTS * sizeof(int), ctx->stream));
+    /* no event timing here (ProfScope creates events): straight to the launch */
+    const bool quad = use_quad(ctx, n);
+    const unsigned blocks = trace_blocks(ctx, n);
+    if (quad) rt_launch_qtrace(false, false, blocks, ctx->stream, ctx->sc, io, ctx->ctrs);
+    else rt_launch_ptrace(false, false, blocks, ctx->stream, ctx->sc, io, ctx->ctrs);
+    HIPCHK(hipGetLastError());
+    return PTR_OK;
 }
 
 int ptr_trace_occluded(PtrContext *ctx, int n, const float *d_o, const float *d_d, const float *d_tmax, int32_t *d_occluded) {

@@ -137,6 +137,10 @@ class Renderer:
     def trace_closest(self, n, d_o, d_d, d_tmax, d_prim, d_face, d_t, d_b0=None, d_b1=None):
         capi.check(capi.hip().ptr_trace_closest(self._ctx, int(n), d_o, d_d, d_tmax, d_prim, d_face, d_t, d_b0, d_b1))
 
+    def trace_closest_noalloc(self, n, d_o, d_d, d_tmax, d_prim, d_face, d_t, d_b0=None, d_b1=None):
+        """ptr_trace_closest_noalloc: same results, no device allocation, cursor in the library's static scratch."""
+        capi.check(capi.hip().ptr_trace_closest_noalloc(self._ctx, int(n), d_o, d_d, d_tmax, d_prim, d_face, d_t, d_b0, d_b1))
+
     def trace_occluded(self, n, d_o, d_d, d_tmax, d_occ):
         capi.check(capi.hip().ptr_trace_occluded(self._ctx, int(n), d_o, d_d, d_tmax, d_occ))
 
