@@ -248,7 +248,7 @@ PD void quad_trace(const DScene &sc, Source src, int *lds /* &stack[quad of this
             else {
                 f3 o, dd;
                 particle_object_ray(ro, rd, f3(q0.x, q0.y, q0.z), &o, &dd);
-                h = sphere_hit_t_obj(o, dd, q1.x, tmax, &t);
+                h = particle_box_test(ro, inv, tmax, f3(q0.x, q0.y, q0.z), q1.x) && sphere_hit_t_obj(o, dd, q1.x, tmax, &t);
                 b0 = 0; b1 = 0;
             }
             h = h && mine;

@@ -380,7 +380,7 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, unsigned *total
                     f3 o, dd;
                     particle_object_ray(ro, rd, f3(q0.x, q0.y, q0.z), &o, &dd);
                     float t;
-                    if (sphere_hit_t_obj(o, dd, q1.x, tmax, &t)) {
+                    if (particle_box_test(ro, inv, tmax, f3(q0.x, q0.y, q0.z), q1.x) && sphere_hit_t_obj(o, dd, q1.x, tmax, &t)) {
                         tmax = t; hp = cp; hf = __float_as_int(q1.w); hb0 = 0; hb1 = 0; hit = true;
                         if (PT_ANY) { ended = true; break; }
                     }
@@ -590,7 +590,7 @@ PD void persistent_trace_sched(const DScene &sc, Source src, int *lds, unsigned 
                     f3 o, dd;
                     particle_object_ray(ro, rd, f3(q0.x, q0.y, q0.z), &o, &dd);
                     float t;
-                    if (sphere_hit_t_obj(o, dd, q1.x, tmax, &t)) {
+                    if (particle_box_test(ro, inv, tmax, f3(q0.x, q0.y, q0.z), q1.x) && sphere_hit_t_obj(o, dd, q1.x, tmax, &t)) {
                         tmax = t; hp = cp; hf = __float_as_int(q1.w); hb0 = 0; hb1 = 0; hit = true;
                         ended = PT_ANY;
                     }

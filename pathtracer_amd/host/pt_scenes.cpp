@@ -338,6 +338,111 @@ void SubsurfaceScene(Camera *camera, Float aspect, int segments) {
     } else InsertPrimitive(MakeSphere(Translate(-60, 20, -20), 18), kd0);
 }
 
+
+/* c3: an indoor room in the manner of CornellRoom (main.cpp:626-711: image-textured rectangle walls, several meshes that
+ * came with their own materials, an emissive rectangle under the ceiling) at the size SURVEY 8(d) gives configs[2]:
+ * 40 rectangle / SDF-box primitives (walls, furniture), 8 knot meshes of 2 * segments^2 triangles each (224 -> 100,352)
+ * standing in for the afrodite / shield OBJ files, one material class each, and 64 small emitters (a ceiling grid of 48
+ * rectangles and 16 sphere bulbs along the walls; the light table holds 256, primitive.h:93).  The wall textures are
+ * generated (the reference loads greek.jpg / orange.png).  No sky: every path stays inside. */
+static std::vector<Spectrum> g_roomTex[2];
+static ImageData g_roomImg[2];
+void RoomScene(Camera *camera, Float aspect, int segments) {
+    camera->Config(Point3f(-1, 7, -29), Point3f(0, 6.0f, 0.0f), vec3f(0, 1, 0), 48, aspect);
+    const Float height = 17, width = 26, zback = 15, zfront = -32;
+    const Float depth = zback - zfront, zmid = 0.5f * (zback + zfront);
+    /* two generated wall textures: a two-tone checker with a frieze band, and a brick pattern */
+    for (int k = 0; k < 2; k++) {
+        const int tw = 256, th = 128;
+        g_roomTex[k].resize((size_t)tw * th);
+        for (int y = 0; y < th; y++)
+            for (int x = 0; x < tw; x++) {
+                Spectrum c;
+                if (k == 0) {
+                    bool chk = ((x / 16) + (y / 16)) & 1;
+                    c = chk ? Spectrum(.80, .74, .62) : Spectrum(.55, .42, .30);
+                    if (y > 96 && y < 112) c = Spectrum(.25, .35, .60);
+                } else {
+                    int row = y / 12, off = (row & 1) ? 12 : 0;
+                    bool mortar = (y % 12) == 0 || ((x + off) % 24) == 0;
+                    c = mortar ? Spectrum(.75, .73, .70) : Spectrum(.62 + .05f * ((row * 7 + (x + off) / 24 * 3) % 4), .30, .22);
+                }
+                g_roomTex[k][(size_t)y * tw + x] = c;
+            }
+        g_roomImg[k].data = g_roomTex[k].data();
+        g_roomImg[k].width = tw;
+        g_roomImg[k].height = th;
+        g_roomImg[k].is_valid = 1;
+    }
+    MaterialDescriptor white = MakeMatteMaterial(Spectrum(.73, .73, .73));
+    MaterialDescriptor orange = MakeMatteMaterial(Spectrum(.73, .53, .33));
+    MaterialDescriptor wood = MakeMatteMaterial(Spectrum(.45, .30, .18), 0.3);
+    MaterialDescriptor dark = MakePlasticMaterial(Spectrum(.08, .08, .09), Spectrum(.5), 0.05);
+    MaterialDescriptor checker = MakeMatteMaterial(MakeTexture(&g_roomImg[0]));
+    MaterialDescriptor brick = MakeMatteMaterial(MakeTexture(&g_roomImg[1]));
+    MaterialDescriptor mirror = MakeMirrorMaterial(Spectrum(.9));
+    MaterialDescriptor glass = MakeGlassMaterial(Spectrum(1), Spectrum(1), 1.5);
+    MaterialDescriptor floorMat = MakeUberMaterial(Spectrum(.35, .33, .30), Spectrum(.25), Spectrum(0), Spectrum(0), 0.05, 0.05, Spectrum(1), 1.5f);
+    int nprim = 0;
+    /* 6 walls */
+    InsertPrimitive(MakeRectangle(Translate(0, height / 2, zback), width, height), checker); nprim++;
+    InsertPrimitive(MakeRectangle(Translate(-width / 2, height / 2, zmid) * RotateY(90), depth, height), brick); nprim++;
+    InsertPrimitive(MakeRectangle(Translate(width / 2, height / 2, zmid) * RotateY(90), depth, height), brick); nprim++;
+    InsertPrimitive(MakeRectangle(Translate(0, 0, zmid) * RotateX(90), width, depth), floorMat); nprim++;
+    InsertPrimitive(MakeRectangle(Translate(0, height, zmid) * RotateX(90), width, depth), white); nprim++;
+    InsertPrimitive(MakeRectangle(Translate(0, height / 2, zfront), width, height), orange); nprim++;
+    /* furniture: a long table (top + 4 legs), two benches (top + 2 legs each), four pedestals, two shelves of three boards, a
+     * wall mirror, two picture rectangles, a glass display box, a rug, four pillars, a door panel: 34 primitives */
+    InsertPrimitive(MakeBox(Translate(0, 3.0, 2), 12, 0.4, 5), wood); nprim++;
+    for (int i = 0; i < 4; i++) { InsertPrimitive(MakeBox(Translate((i & 1) ? 5.5 : -5.5, 1.4, (i & 2) ? 4.0 : 0.0), 0.5, 2.8, 0.5), wood); nprim++; }
+    for (int b = 0; b < 2; b++) {
+        Float x = b ? 9.5 : -9.5;
+        InsertPrimitive(MakeBox(Translate(x, 1.6, -8) * RotateY(b ? 12 : -12), 3, 0.3, 7), dark); nprim++;
+        InsertPrimitive(MakeBox(Translate(x, 0.75, -10.5), 2.4, 1.5, 0.4), dark); nprim++;
+        InsertPrimitive(MakeBox(Translate(x, 0.75, -5.5), 2.4, 1.5, 0.4), dark); nprim++;
+    }
+    for (int i = 0; i < 4; i++) { InsertPrimitive(MakeBox(Translate(-9 + 6 * i, 1.0, 10.5) * RotateY(15 * i), 2.4, 2.0, 2.4), white); nprim++; }
+    for (int sft = 0; sft < 2; sft++)
+        for (int i = 0; i < 3; i++) { InsertPrimitive(MakeBox(Translate(sft ? 12.4 : -12.4, 5 + 3 * i, 6), 1.0, 0.25, 8), wood); nprim++; }
+    InsertPrimitive(MakeRectangle(Translate(-width / 2 + 0.02, 8, -12) * RotateY(90), 7, 9), mirror); nprim++;
+    InsertPrimitive(MakeRectangle(Translate(-5, 11, zback - 0.02), 6, 4), MakeMatteMaterial(Spectrum(.15, .35, .25))); nprim++;
+    InsertPrimitive(MakeRectangle(Translate(6, 11, zback - 0.02), 5, 5), MakeMatteMaterial(Spectrum(.55, .15, .12))); nprim++;
+    InsertPrimitive(MakeBox(Translate(0, 4.45, 2) * RotateY(20), 2.5, 2.5, 2.5), glass); nprim++;
+    InsertPrimitive(MakeRectangle(Translate(0, 0.01, -10) * RotateX(90), 9, 12), MakeMatteMaterial(Spectrum(.45, .12, .12), 0.5)); nprim++;
+    for (int i = 0; i < 4; i++) { InsertPrimitive(MakeBox(Translate((i & 1) ? 11.5 : -11.5, height / 2, (i & 2) ? 13.5 : -20.0), 1.5, height, 1.5), white); nprim++; }
+    InsertPrimitive(MakeBox(Translate(8, 4.5, zfront + 0.3), 4, 9, 0.3), wood); nprim++;
+    InsertPrimitive(MakeBox(Translate(-8.5, 1.5, -24) * RotateY(8), 5, 3, 1.8), wood); nprim++;   /* a low cabinet */
+    InsertPrimitive(MakeBox(Translate(-3, 0.9, -4) * RotateY(30), 1.4, 1.8, 1.4), dark); nprim++; /* two stools */
+    InsertPrimitive(MakeBox(Translate(3.2, 0.9, -3) * RotateY(-20), 1.4, 1.8, 1.4), dark); nprim++;
+    (void)nprim; /* 40 */
+    /* 8 meshes, one material class each (CornellRoom gets its materials from the .mtl files) */
+    MaterialDescriptor meshMats[8] = {
+        MakeMatteMaterial(Spectrum(.70, .68, .62), 0.2),
+        MakePlasticMaterial(Spectrum(.15, .25, .55), Spectrum(.5), 0.05),
+        MakeMetalMaterial(Spectrum(.2, .92, 1.1), Spectrum(3.9, 2.45, 2.14), .05, .05),
+        MakeGlassMaterial(Spectrum(1), Spectrum(1), 1.5, .05, .05),
+        MakeUberMaterial(Spectrum(.05), Spectrum(.8), Spectrum(0), Spectrum(0), 0.001, 0.001, Spectrum(1), 1.5f), /* main.cpp:636 */
+        MakeTranslucentMaterial(Spectrum(.5, .4, .3), Spectrum(.3), Spectrum(.6), Spectrum(.4), .2),
+        MakeMirrorMaterial(Spectrum(.85, .8, .6)),
+        MakeMatteMaterial(MakeTexture(&g_roomImg[0])),
+    };
+    for (int m = 0; m < 8; m++) {
+        Transform T;
+        if (m < 4) T = Translate(-9 + 6 * m, 3.6, 10.5) * Scale(0.42) * RotateY(40 * m) * RotateX(90); /* on the pedestals */
+        else if (m < 6) T = Translate(m == 4 ? -3.5 : 3.5, 4.4, 2) * Scale(0.36) * RotateY(25 * m) * RotateX(70); /* on the table */
+        else T = Translate(m == 6 ? -6 : 6, 2.2, -14) * Scale(0.62) * RotateY(-30 * m) * RotateX(90); /* on the floor */
+        InsertPrimitive(MakeMesh(MakeKnotMesh(segments, segments, 20 + m, T)), meshMats[m]);
+    }
+    /* 64 emitters: 8 x 6 downlights just under the ceiling, 16 bulbs along the side walls */
+    MaterialDescriptor down = MakeEmissive(Spectrum(0.992, 0.964, 0.790) * 14);
+    for (int i = 0; i < 8; i++)
+        for (int j = 0; j < 6; j++)
+            InsertPrimitive(MakeRectangle(Translate(-10.5 + 3.0 * i, height - 0.01, zfront + 4 + (depth - 8) * j / 5.0) * RotateX(90), 0.9, 0.9), down);
+    MaterialDescriptor bulb = MakeEmissive(Spectrum(1.0, 0.75, 0.45) * 25);
+    for (int i = 0; i < 16; i++)
+        InsertPrimitive(MakeSphere(Translate((i & 1) ? 12.3 : -12.3, 12.5, zfront + 3 + (depth - 6) * (i / 2) / 7.0), 0.28), bulb);
+}
+
 struct BuiltScene {
     FlatSceneHolder *flat;
     Camera camera;
@@ -348,7 +453,7 @@ struct BuiltScene {
 
 extern "C" {
 
-/* name: "cornell" | "knot" | "zoo" | "volcaustic" | "fluid" | "subsurface" | "origami" | "furnace"; p0/p1: size and variant */
+/* name: "cornell" | "knot" | "zoo" | "volcaustic" | "fluid" | "subsurface" | "origami" | "furnace" | "room"; p0/p1: size and variant */
 void *pth_scene_build(const char *name, int width, int height, int p0, int p1) {
     std::string n(name);
     BuiltScene *b = new BuiltScene();
@@ -365,6 +470,7 @@ void *pth_scene_build(const char *name, int width, int height, int p0, int p1) {
     else if (n == "fluid") FluidScene(&b->camera, aspect, p0 > 0 ? p0 : 4000000);
     else if (n == "subsurface") SubsurfaceScene(&b->camera, aspect, p0);
     else if (n == "origami") OrigamiScene(&b->camera, aspect);
+    else if (n == "room") RoomScene(&b->camera, aspect, p0 > 0 ? p0 : 224);
     else { delete b; return nullptr; }
     b->flat = FlattenScene();
     return b;

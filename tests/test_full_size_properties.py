@@ -1,5 +1,7 @@
-"""BASELINE.json's full-size configuration (871,200 triangles, 1920x1080) is too large for the
-oracle to finish in seconds, so it is checked through size-independent properties: closest-hit
+"""BASELINE.json's full-size configurations - configs[1] 871,200-triangle knot at 1080p, configs[2] the room (8 x 100,352
+triangles, 40 analytic primitives, 64 emitters) at 1080p, configs[3] 4 M particle spheres at 3840x2160, configs[4] a
+299,538-triangle subsurface knot and the volumetric-caustics scene at 1080p - are too large for the
+oracle to finish in seconds, so they are checked through size-independent properties: closest-hit
 distances agree with brute-force-free invariants (any-hit consistency, t monotonicity under a
 shorter tmax), per-sample streams are independent of batching, and a strided sample of the
 primary rays is compared with the oracle exactly."""
@@ -14,23 +16,45 @@ pytestmark = pytest.mark.gpu
 FMAX = np.finfo(np.float32).max
 
 
-@pytest.fixture(scope="module")
-def big(cuda):
-    W, H = 1920, 1080
-    sc = pa.BuiltScene("knot", W, H, 660, 0)
+# name: (family, p0, p1, width, height, integrator, least fraction of camera rays that hit something)
+CONFIGS = {
+    "c1_knot": ("knot", 660, 0, 1920, 1080, pa.LI_VOLPATH, 0.2),            # the ground sphere fills the lower half of the frame
+    "c2_room": ("room", 224, 0, 1920, 1080, pa.LI_PATHSAMPLED, 0.999),      # closed room
+    "c3_fluid": ("fluid", 4000000, 0, 3840, 2160, pa.LI_VOLPATH, 0.5),
+    "c4_subsurface": ("subsurface", 387, 0, 1920, 1080, pa.LI_VOLPATH, 0.3),
+    "c4_volcaustic": ("volcaustic", 0, 0, 1920, 1080, pa.LI_VOLPATH, 0.3),
+}
+
+
+@pytest.fixture(scope="module", params=list(CONFIGS))
+def big(cuda, request):
+    fam, p0, p1, W, H, integ, min_hit = CONFIGS[request.param]
+    sc = pa.BuiltScene(fam, W, H, p0, p1)
     r = pa.Renderer(0)
     r.upload(sc)
     r.set_camera(sc.camera)
     r.film_init(W, H, 3)
+    sc.integ, sc.min_hit = integ, min_hit
     yield sc, r, W, H
     r.close()
+    sc.close()
 
 
 def test_bvh_shape(big):
     sc, r, W, H = big
+    f = sc.flat.contents
+    want = sum(f.meshes[i].n_triangles for i in range(f.n_meshes)) + sum(f.clouds[i].n_particles for i in range(f.n_clouds))
     info = r.bvh_info()
-    assert info["items"] == 871200  # every triangle exactly once (analytic primitives are not BVH items)
-    assert info["nodes"] < info["items"]
+    assert info["items"] == want  # every triangle / particle exactly once (analytic primitives are not BVH items)
+    if sc.name == "knot":
+        assert want == 871200
+    if sc.name == "room":
+        assert want == 8 * 100352 and f.n_primitives == 112
+    if sc.name == "fluid":
+        assert want > 3900000
+    if sc.name == "subsurface":
+        assert want == 2 * 387 * 387
+    assert info["nodes"] < max(info["items"], 1)
     assert info["bytes"] == 128 * info["nodes"] + 48 * info["items"]
 
 
@@ -41,17 +65,28 @@ def test_closest_vs_occluded_consistency(big):
     tmax = np.full(n, FMAX, np.float32)
     g = common.gpu_trace_closest(r, o, d, tmax)
     hit = g["prim"] >= 0
-    assert 0.2 < hit.mean() <= 1.0  # the ground sphere fills the lower half of the frame
+    assert sc.min_hit <= hit.mean() <= 1.0
     # any-hit with the same extent agrees with closest-hit on hit / miss
     occ = common.gpu_trace_occluded(r, o, d, tmax)
     assert np.array_equal(occ != 0, hit)
     # shortening the segment to just before the hit must clear it; to just after must keep the same hit
     t_short = np.where(hit, g["t"] * np.float32(0.999), tmax).astype(np.float32)
     occ2 = common.gpu_trace_occluded(r, o, d, t_short)
-    # a nearer surface cannot exist (closest), so nothing may be hit within 0.999 t
-    assert (occ2[hit] != 0).mean() < 1e-4
+    # a nearer surface cannot exist (closest), so nothing may be hit within 0.999 t (SDF shapes accept a hit within
+    # 1e-3 t of their surface, procedural.cpp:221, so a marched ray may stop just short of the shortened segment's end)
+    assert (occ2[hit] != 0).mean() < (2e-2 if sc.name in ("room",) else 1e-4)
     g2 = common.gpu_trace_closest(r, o, d, np.where(hit, g["t"] * np.float32(1.001), tmax).astype(np.float32))
-    assert np.array_equal(g2["prim"], g["prim"]) and np.array_equal(g2["t"][hit], g["t"][hit])
+    # ... for the shapes whose answer does not depend on tMax: a rectangle's hit lies in front of its own bounds
+    # (rectangle.cpp:8 vs :37-40), so a tMax just behind the hit can cull its box; SDF marching stops at tMax (procedural.cpp:214)
+    f = sc.flat.contents
+    exact = np.array([f.primitives[i].shape_type in (pa.capi.SHAPE_SPHERE, pa.capi.SHAPE_MESH, pa.capi.SHAPE_PARTICLECLOUD)
+                      for i in range(f.n_primitives)])
+    sel = hit & exact[np.maximum(g["prim"], 0)]
+    assert sel.mean() > 0.05
+    same = (g2["prim"] == g["prim"]) & (g2["face"] == g["face"])
+    # (the oracle loses the same ~1e-4 of the grazing sphere / particle hits when tMax is pulled in: reference semantics)
+    assert same[sel].mean() > 0.9995
+    assert np.array_equal(g2["t"][sel & same], g["t"][sel & same])
 
 
 def test_strided_primary_rays_against_oracle(big):
@@ -76,7 +111,7 @@ def test_full_frame_render_counts(big):
     sc, r, W, H = big
     r.film_init(W, H, 3)
     r.counters_reset()
-    r.render(2, pa.LI_VOLPATH)
+    r.render(2, sc.integ)
     we, acc, smp = r.film()
     c = r.counters()
     assert (smp == 2).all() and np.isfinite(we).all() and (acc > 0).all()
@@ -84,7 +119,7 @@ def test_full_frame_render_counts(big):
     assert c["total_paths"] >= c["camera_rays"] and c["misses"] <= c["total_paths"]
     # the same two samples rendered one at a time give the same film, bit for bit
     r.film_init(W, H, 3)
-    r.render(1, pa.LI_VOLPATH)
-    r.render(1, pa.LI_VOLPATH)
+    r.render(1, sc.integ)
+    r.render(1, sc.integ)
     we2, _, _ = r.film()
     assert np.array_equal(we, we2)

@@ -4,6 +4,9 @@ ray whose reference answer does not depend on the reference's own BVH order (exa
 by the oracle); t and barycentrics within 1e-5 relative; images at equal spp within the stated
 mean-relative-error / relative-RMSE bounds (device libm differs from glibc by ulps, which flips a
 discrete sampling decision on a small fraction of paths)."""
+import json
+import os
+
 import numpy as np
 import pytest
 
@@ -99,7 +102,15 @@ def test_empty_and_single_ray(scenes):
     check_closest(common.gpu_trace_closest(r, ro, rd, tmax), o.trace_closest(ro, rd, tmax))
 
 
-# image parity: (mean relative error, relative RMSE, fraction of pixels off by > 1e-3 relative)
+# image parity: (mean relative error, relative RMSE, fraction of pixels off by > 1e-3 relative).
+# Bounds per case = 10 x the residual measured on the MI355X (tests/image_bounds.json, written by this test when
+# PT_RECORD_IMAGE_STATS names a file, then scaled by tests/make_image_bounds.py), never looser than the ceiling below.
+# The residual comes from device libm (sinf / cosf / expf / logf / powf / atan2f / acosf differ from glibc by ulps), which
+# flips a discrete sampling decision on a fraction of a per cent of the paths.
+IMAGE_CEILING = (5e-3, 5e-2, 0.02)
+IMAGE_FLOOR = (1e-5, 2e-4, 4e-3)  # one flipped sampling decision in a 32 x 24 frame moves a case by about this much
+_bounds_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "image_bounds.json")
+IMAGE_BOUNDS = json.load(open(_bounds_path)) if os.path.exists(_bounds_path) else {}
 IMAGE_CASES = [(s, i) for s in common.SCENES for i in common.INTEGRATORS]
 @pytest.mark.parametrize("name,integ", IMAGE_CASES)
 def test_image(scenes, name, integ):
@@ -117,9 +128,15 @@ def test_image(scenes, name, integ):
     assert np.isfinite(img).all()
     assert np.array_equal(smp.reshape(-1), osmp)
     mean_rel, rmse_rel, off = common.image_stats(img, ref)
-    assert mean_rel < 5e-3, (mean_rel, rmse_rel, off)
-    assert rmse_rel < 5e-2, (mean_rel, rmse_rel, off)
-    assert off < 0.02, (mean_rel, rmse_rel, off)
+    rec = os.environ.get("PT_RECORD_IMAGE_STATS")
+    if rec:
+        with open(rec, "a") as f:
+            f.write(json.dumps({"case": "%s/%s" % (name, integ), "mean_rel": mean_rel, "rmse_rel": rmse_rel, "off": off}) + "\n")
+    bound = IMAGE_BOUNDS.get("%s/%s" % (name, integ), IMAGE_CEILING)
+    bound = [min(max(b, f), c) for b, f, c in zip(bound, IMAGE_FLOOR, IMAGE_CEILING)]
+    assert mean_rel <= bound[0], (mean_rel, rmse_rel, off, bound)
+    assert rmse_rel <= bound[1], (mean_rel, rmse_rel, off, bound)
+    assert off <= bound[2], (mean_rel, rmse_rel, off, bound)
     gc, oc = r.counters(), o.counters()
     assert gc["camera_rays"] == oc["camera_rays"] == W * H * spp
     for k in ("total_paths", "shadow_rays", "mis_rays", "surface_hits", "medium_hits", "misses"):
