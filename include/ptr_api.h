@@ -204,6 +204,15 @@ typedef struct {
     uint64_t prims_tested;   /* leaf items tested by trace kernels (profiling builds)     */
 } PtrCounters;
 
+/* What the stages of the wavefront pipeline processed since the last ptr_counters_reset (no counterpart in the
+ * reference: its megakernel has no stages).  Used by bench.py to price the kernels against their rooflines. */
+typedef struct {
+    uint64_t finish_paths;    /* extension rays traced inside the finish kernel (not by a tracer launch)   */
+    uint64_t finish_nee_rays; /* shadow + MIS rays traced inside the finish kernel                         */
+    uint64_t shaded_vertices; /* path vertices the shade kernel processed (hits that survived the miss pre-pass) */
+    uint64_t nee_records;     /* of those, vertices that wrote a direct-light record                        */
+} PtrPipelineStats;
+
 /* One entry per kernel family; filled by ptr_profile_read when profiling is on. */
 #define PTR_PROF_KERNELS 10
 typedef struct {
@@ -237,6 +246,13 @@ int ptr_set_stream(PtrContext *ctx, void *hip_stream);
  * mesh.cpp:643-671, particlecloud.cpp:310-337) and MakeLights<<<1,1>>> (scene.cpp:948).
  * Flattens, builds the compact BVH on the host, uploads. */
 int ptr_scene_upload(PtrContext *ctx, const PtrFlatScene *scene);
+/* The same in two steps, for several contexts (GPUs) that render one scene: ptr_scene_build does the host half once
+ * (flattening, both BVH builds, tables; draws from libc rand() like Aggregator::Wrap), ptr_scene_upload_built copies the
+ * result to a context's device.  ptr_scene_upload = build + upload_built + free. */
+typedef struct PtrBuiltScene PtrBuiltScene;
+int ptr_scene_build(const PtrFlatScene *scene, PtrBuiltScene **out);
+int ptr_scene_upload_built(PtrContext *ctx, const PtrBuiltScene *built);
+int ptr_scene_built_free(PtrBuiltScene *built);
 /* Replaces Camera::Config's writes into the managed Camera (camera.cpp:145-197). */
 int ptr_camera_set(PtrContext *ctx, const PtrCamera *cam);
 
@@ -248,6 +264,14 @@ int ptr_film_init(PtrContext *ctx, int width, int height, uint64_t seed);
 /* Multi-GPU sharding (no counterpart; the reference is single-device): this context
  * renders only sample indices s with s % stride == offset.  Default (0,1). */
 int ptr_film_shard(PtrContext *ctx, int sample_offset, int sample_stride);
+/* Multi-GPU sharding by image tiles (no counterpart): the film is cut into PTR_TILE x PTR_TILE pixel tiles, numbered row
+ * by row, and this context renders only the tiles t with t % tile_stride == tile_offset - every sample of their pixels,
+ * with the same per-pixel RNG keys as an unsharded render.  The other pixels of its film stay as they are (zero after
+ * ptr_film_init), so summing the films of all shards gives the unsharded film BIT FOR BIT (x + 0 = x), whatever the
+ * number of shards.  (0, 1) = the whole film; ptr_film_init resets to that.  Needs a film.  May be combined with
+ * ptr_film_shard. */
+#define PTR_TILE 8
+int ptr_film_tiles(PtrContext *ctx, int tile_offset, int tile_stride);
 /* Replaces Render<<<blocks,threads>>>(image, scene, camera, ns) (main.cpp:421-457,1139):
  * ns more samples for every pixel with integrator PTR_LI_*.  Asynchronous, and ordered with the
  * context's stream (ptr_set_stream; default: the null stream) on both sides: the passes run on internal
@@ -282,6 +306,8 @@ int ptr_film_device_ptrs(PtrContext *ctx, void **we_rgb, void **acc_weight, void
 /* Replaces ImageStats (camera.cpp:86-125). Synchronises. */
 int ptr_counters_read(PtrContext *ctx, PtrCounters *out);
 int ptr_counters_reset(PtrContext *ctx);
+/* Stage statistics (above); cleared by ptr_counters_reset.  Synchronises. */
+int ptr_pipeline_stats_read(PtrContext *ctx, PtrPipelineStats *out);
 
 /* ---- hot-path stages exposed for parity tests and benchmarks ------------------------ */
 

@@ -89,6 +89,10 @@ class PtrCounters(C.Structure):
         return {n: int(getattr(self, n)) for n in COUNTER_NAMES}
 
 
+class PtrPipelineStats(C.Structure):
+    _fields_ = [(n, u64) for n in ("finish_paths", "finish_nee_rays", "shaded_vertices", "nee_records")]
+
+
 class PtrKernelProfile(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("launches", u64), ("total_ms", C.c_double), ("items", u64)]
 
@@ -101,9 +105,13 @@ HIP_SIGNATURES = {
     "ptr_last_error": (C.c_char_p, []),
     "ptr_set_stream": (C.c_int, [CTX, C.c_void_p]),
     "ptr_scene_upload": (C.c_int, [CTX, C.POINTER(PtrFlatScene)]),
+    "ptr_scene_build": (C.c_int, [C.POINTER(PtrFlatScene), C.POINTER(C.c_void_p)]),
+    "ptr_scene_upload_built": (C.c_int, [CTX, C.c_void_p]),
+    "ptr_scene_built_free": (C.c_int, [C.c_void_p]),
     "ptr_camera_set": (C.c_int, [CTX, C.POINTER(PtrCamera)]),
     "ptr_film_init": (C.c_int, [CTX, C.c_int, C.c_int, u64]),
     "ptr_film_shard": (C.c_int, [CTX, C.c_int, C.c_int]),
+    "ptr_film_tiles": (C.c_int, [CTX, C.c_int, C.c_int]),
     "ptr_render": (C.c_int, [CTX, C.c_int, C.c_int]),
     "ptr_sync": (C.c_int, [CTX]),
     "ptr_film_read": (C.c_int, [CTX, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -116,6 +124,7 @@ HIP_SIGNATURES = {
     "ptr_trace_closest": (C.c_int, [CTX, C.c_int] + [C.c_void_p] * 8),
     "ptr_trace_closest_noalloc": (C.c_int, [CTX, C.c_int] + [C.c_void_p] * 8),
     "ptr_trace_occluded": (C.c_int, [CTX, C.c_int] + [C.c_void_p] * 4),
+    "ptr_pipeline_stats_read": (C.c_int, [CTX, C.POINTER(PtrPipelineStats)]),
     "ptr_profile_enable": (C.c_int, [CTX, C.c_int]),
     "ptr_profile_reset": (C.c_int, [CTX]),
     "ptr_profile_read": (C.c_int, [CTX, C.POINTER(PtrKernelProfile), C.c_int, C.POINTER(C.c_int)]),
@@ -190,6 +199,35 @@ def host():
             raise RuntimeError("pathtracer_amd: %s is missing - build it with `make -C pathtracer_amd`" % HOST_LIB)
         _host = _bind(C.CDLL(HOST_LIB), HOST_SIGNATURES)
     return _host
+
+
+MULTIGPU_LIB = os.path.join(LIB_DIR, "libpt_multigpu.so")
+MULTIGPU_SIGNATURES = {
+    "RenderGroupCreate": (C.c_void_p, [C.c_int, C.POINTER(C.c_int), C.c_int]),
+    "RenderGroupFree": (None, [C.c_void_p]),
+    "RenderGroupSize": (C.c_int, [C.c_void_p]),
+    "RenderGroupContext": (CTX, [C.c_void_p, C.c_int]),
+    "RenderGroupUpload": (C.c_int, [C.c_void_p, C.POINTER(PtrFlatScene)]),
+    "RenderGroupCamera": (C.c_int, [C.c_void_p, C.POINTER(PtrCamera)]),
+    "RenderGroupFilmInit": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint64]),
+    "RenderGroupRenderSamples": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "RenderGroupReduce": (C.c_int, [C.c_void_p]),
+    "RenderGroupSync": (C.c_int, [C.c_void_p]),
+    "RenderGroupFilmRead": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "RenderGroupLastError": (C.c_char_p, []),
+}
+_multigpu = None
+
+
+def multigpu():
+    """The C++ multi-GPU host driver (host/pt_multigpu.cpp): RCCL called directly, one process for all GPUs of the node."""
+    global _multigpu
+    if _multigpu is None:
+        host()
+        if not os.path.exists(MULTIGPU_LIB):
+            raise RuntimeError("pathtracer_amd: %s is missing - build it with `make -C pathtracer_amd`" % MULTIGPU_LIB)
+        _multigpu = _bind(C.CDLL(MULTIGPU_LIB), MULTIGPU_SIGNATURES)
+    return _multigpu
 
 
 class PtrError(RuntimeError):

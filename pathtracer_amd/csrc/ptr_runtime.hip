@@ -50,7 +50,7 @@ PD void camera_ray(const DCamera &c, const PassParams &pp, int pixel, int sample
 __global__ void __launch_bounds__(TPB) k_raygen(DScene sc, DCamera cam, Pipe pp, PassParams prm, int n) {
     int slot = blockIdx.x * TPB + threadIdx.x;
     if (slot >= n) return;
-    int pixel = slot % prm.npix;
+    int pixel = pass_pixel(prm, slot);
     int sample = prm.sample_first + (slot / prm.npix) * prm.sample_step;
     f3 o, d;
     float w;
@@ -259,14 +259,16 @@ __global__ void __launch_bounds__(TPB) k_nee_resolve(DScene sc, Pipe pp, const i
 }
 
 /* Render()'s accumulation (main.cpp:449-455): we += weight * L per sample, in sample order */
-__global__ void __launch_bounds__(TPB) k_film(Pipe pp, int npix, int nbatch, float *we, double *acc, long long *samples) {
+__global__ void __launch_bounds__(TPB) k_film(Pipe pp, int npix, const int *pix_map, int nbatch, float *we, double *acc, long long *samples) {
     int p = blockIdx.x * TPB + threadIdx.x;
     if (p >= npix) return;
+    const int lp = p; /* pixel of the pass */
+    p = pix_map ? pix_map[lp] : lp; /* pixel of the film */
     f3 out(we[3 * p], we[3 * p + 1], we[3 * p + 2]);
     double a = acc[p];
     for (int b = 0; b < nbatch; b++) {
         PathRec ps;
-        const int slot = b * npix + p;
+        const int slot = b * npix + lp;
         soa_load<0, 3>(pp.paths, pp.cap, slot, &ps);
         soa_load<WORD_OF(PathRec, weight), WORD_OF(PathRec, weight) + 1>(pp.paths, pp.cap, slot, &ps);
         out += ps.weight * ld3(ps.L);
@@ -362,6 +364,9 @@ struct PtrContext {
     double *acc = nullptr;
     long long *samples = nullptr;
     int sample_cursor = 0, shard_offset = 0, shard_stride = 1;
+    /* tile sharding (ptr_film_tiles): the pixels of this context's 8x8 tiles, in tile order; null = the whole film */
+    int *pix_map = nullptr;
+    int npix_local = 0, tile_offset = 0, tile_stride = 1;
     unsigned char *rgb8 = nullptr; /* 3 * npix bytes: where ptr_film_rgb8 resolves the film before the copy to the host */
     hipEvent_t entry = nullptr;    /* recorded on the caller's stream when ptr_render is entered: the lanes wait for it */
     bool debug_sync = false;       /* PTR_DEBUG_SYNC=1: wait and check for errors after every stage of a pass */
@@ -420,6 +425,8 @@ static void free_film(PtrContext *ctx) {
     for (void *p : film)
         if (p) (void)hipFree(p);
     ctx->we = nullptr; ctx->acc = nullptr; ctx->samples = nullptr; ctx->rgb8 = nullptr;
+    if (ctx->pix_map) (void)hipFree(ctx->pix_map);
+    ctx->pix_map = nullptr;
     if (!ctx->staged_fixed) ctx->staged_bounces = 6; /* the feedback below belongs to the buffers that go away */
     for (Lane &l : ctx->lanes) {
         void *ptrs[] = {l.pipe.ro, l.pipe.rd, l.pipe.hprim, l.pipe.hface, l.pipe.ht, l.pipe.paths, l.pipe.nee,
@@ -603,14 +610,15 @@ static void enqueue_resolve(PtrContext *ctx, Lane &l, int n_upper, int cslot) {
 static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int step, int nb, int integrator) {
     PassParams prm;
     prm.seed = ctx->seed;
-    prm.npix = ctx->npix;
+    prm.npix = ctx->npix_local;
+    prm.pix_map = ctx->pix_map;
     prm.width = ctx->width;
     prm.height = ctx->height;
     prm.sample_first = first;
     prm.sample_step = step;
     prm.integrator = integrator;
     hipStream_t s = l.stream;
-    const int slots = ctx->npix * nb;
+    const int slots = ctx->npix_local * nb;
     /* feedback: if the pass this lane ran before has completed, look at how fast it thinned out and
      * stage bounces only while more than ~0.1 % of the paths are alive (at 64 M slots: 0.4 % -> 1654, 0.1 % -> 1707, 0.025 % -> 1689 Mrays/s) */
     if (!ctx->staged_fixed && l.staged_used > 0 && hipEventQuery(l.film_done) == hipSuccess) {
@@ -729,8 +737,9 @@ static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int ste
     if (ctx->last_film_lane >= 0 && ctx->last_film_lane != lane_index)
         HIPCHK(hipStreamWaitEvent(s, ctx->lanes[ctx->last_film_lane].film_done, 0));
     {
-        ProfScope ps(ctx, s, K_FILM, (uint64_t)ctx->npix);
-        hipLaunchKernelGGL(k_film, dim3(nblocks(ctx->npix)), dim3(TPB), 0, s, l.pipe, ctx->npix, nb, ctx->we, ctx->acc, ctx->samples);
+        ProfScope ps(ctx, s, K_FILM, (uint64_t)ctx->npix_local);
+        hipLaunchKernelGGL(k_film, dim3(nblocks(ctx->npix_local)), dim3(TPB), 0, s, l.pipe, ctx->npix_local, (const int *)ctx->pix_map, nb, ctx->we, ctx->acc,
+                           ctx->samples);
     }
     HIPCHK(hipMemcpyAsync(l.counts_host, l.counts, 4 * MAX_ITERS * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipEventRecord(l.film_done, s));
@@ -742,6 +751,7 @@ static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int ste
 extern "C" {
 
 int ptr_destroy(PtrContext *ctx);
+int ptr_scene_upload_built(PtrContext *ctx, const PtrBuiltScene *built);
 const char *ptr_last_error(void) { return g_err.c_str(); }
 
 int ptr_create(int device, PtrContext **out) {
@@ -835,13 +845,42 @@ int ptr_set_stream(PtrContext *ctx, void *hip_stream) {
     return PTR_OK;
 }
 
+struct PtrBuiltScene {
+    HostScene hs;
+};
+
+int ptr_scene_build(const PtrFlatScene *scene, PtrBuiltScene **out) {
+    if (!out) return set_err(PTR_ERR_INVALID, "null out pointer");
+    *out = nullptr;
+    PtrBuiltScene *b = new PtrBuiltScene();
+    std::string err;
+    int rc = ptr_flatten(scene, &b->hs, &err);
+    if (rc) {
+        delete b;
+        return set_err(rc, err);
+    }
+    *out = b;
+    return PTR_OK;
+}
+int ptr_scene_built_free(PtrBuiltScene *built) {
+    delete built;
+    return PTR_OK;
+}
 int ptr_scene_upload(PtrContext *ctx, const PtrFlatScene *scene) {
+    if (!ctx) return set_err(PTR_ERR_INVALID, "null context");
+    PtrBuiltScene *b = nullptr;
+    int rc = ptr_scene_build(scene, &b);
+    if (rc) return rc;
+    rc = ptr_scene_upload_built(ctx, b);
+    ptr_scene_built_free(b);
+    return rc;
+}
+
+int ptr_scene_upload_built(PtrContext *ctx, const PtrBuiltScene *built) {
     int rc = ctx_use(ctx);
     if (rc) return rc;
-    HostScene hs;
-    std::string err;
-    rc = ptr_flatten(scene, &hs, &err);
-    if (rc) return set_err(rc, err);
+    if (!built) return set_err(PTR_ERR_INVALID, "null built scene");
+    const HostScene &hs = built->hs;
     if ((rc = sync_all(ctx))) return rc;
     free_scene(ctx);
     DScene sc;
@@ -1022,6 +1061,11 @@ int ptr_film_init(PtrContext *ctx, int width, int height, uint64_t seed) {
     ctx->width = width;
     ctx->height = height;
     ctx->npix = npix;
+    if (ctx->pix_map) (void)hipFree(ctx->pix_map); /* a new film belongs to this context whole until ptr_film_tiles says otherwise */
+    ctx->pix_map = nullptr;
+    ctx->npix_local = npix;
+    ctx->tile_offset = 0;
+    ctx->tile_stride = 1;
     ctx->seed = seed;
     ctx->sample_cursor = 0;
     ctx->last_film_lane = -1;
@@ -1038,6 +1082,35 @@ int ptr_film_shard(PtrContext *ctx, int sample_offset, int sample_stride) {
     if (sample_stride < 1 || sample_offset < 0 || sample_offset >= sample_stride) return set_err(PTR_ERR_INVALID, "bad shard (offset, stride)");
     ctx->shard_offset = sample_offset;
     ctx->shard_stride = sample_stride;
+    return PTR_OK;
+}
+
+int ptr_film_tiles(PtrContext *ctx, int tile_offset, int tile_stride) {
+    int rc = ctx_use(ctx);
+    if (rc) return rc;
+    if (!ctx->has_film) return set_err(PTR_ERR_STATE, "ptr_film_tiles needs a film");
+    if (tile_stride < 1 || tile_offset < 0 || tile_offset >= tile_stride) return set_err(PTR_ERR_INVALID, "bad tile shard (offset, stride)");
+    if ((rc = sync_all(ctx))) return rc;
+    if (ctx->pix_map) (void)hipFree(ctx->pix_map);
+    ctx->pix_map = nullptr;
+    ctx->npix_local = ctx->npix;
+    ctx->tile_offset = tile_offset;
+    ctx->tile_stride = tile_stride;
+    if (tile_stride == 1) return PTR_OK;
+    const int T = PTR_TILE, tx = (ctx->width + T - 1) / T, ty = (ctx->height + T - 1) / T;
+    std::vector<int> map;
+    map.reserve((size_t)ctx->npix / tile_stride + T * T);
+    for (int t = tile_offset; t < tx * ty; t += tile_stride) {
+        const int x0 = (t % tx) * T, y0 = (t / tx) * T;
+        for (int y = y0; y < y0 + T && y < ctx->height; y++)
+            for (int x = x0; x < x0 + T && x < ctx->width; x++) map.push_back(y * ctx->width + x);
+    }
+
+    ctx->npix_local = (int)map.size();
+    if (!map.empty()) {
+        HIPCHK(hipMalloc((void **)&ctx->pix_map, map.size() * sizeof(int)));
+        HIPCHK(hipMemcpy(ctx->pix_map, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
     return PTR_OK;
 }
 
@@ -1058,11 +1131,16 @@ int ptr_render(PtrContext *ctx, int ns, int integrator) {
     int stride = ctx->shard_stride;
     int first = begin + ((ctx->shard_offset - begin) % stride + stride) % stride;
     bool used[N_LANES] = {};
+    if (ctx->npix_local == 0) return PTR_OK; /* a tile shard without tiles */
+    /* samples per pass: what the pass buffers hold of this context's pixels */
+    long long nb_cap = (long long)ctx->lanes[0].pipe.cap / ctx->npix_local;
+    if (nb_cap > 64) nb_cap = 64;
+    if (nb_cap < 1) nb_cap = 1;
     while (first < end) {
         int remaining = (end - first + stride - 1) / stride;
         /* spread the samples of this call over the lanes before filling a lane's batch */
         int nb = (remaining + ctx->spread - 1) / ctx->spread;
-        if (nb > ctx->nb_max) nb = ctx->nb_max;
+        if (nb > (int)nb_cap) nb = (int)nb_cap;
         if (nb < 1) nb = 1;
         int li = ctx->next_lane++ % N_LANES;
         rc = run_pass(ctx, ctx->lanes[li], li, first, stride, nb, integrator);
@@ -1152,6 +1230,22 @@ int ptr_counters_read(PtrContext *ctx, PtrCounters *out) {
         for (int r = 0; r < CTR_REPLICAS; r++) sum[c] += copies[r * CTR_STRIDE + c];
     }
     out->camera_rays = ctx->camera_rays;
+    return PTR_OK;
+}
+
+int ptr_pipeline_stats_read(PtrContext *ctx, PtrPipelineStats *out) {
+    int rc = ctx_use(ctx);
+    if (rc) return rc;
+    if (!out) return set_err(PTR_ERR_INVALID, "null out pointer");
+    static_assert(sizeof(PtrPipelineStats) == (CX_END - C_COUNT) * sizeof(uint64_t), "statistics layout");
+    if ((rc = sync_all(ctx))) return rc;
+    unsigned long long copies[CTR_REPLICAS * CTR_STRIDE];
+    HIPCHK(hipMemcpy(copies, ctx->ctrs, sizeof(copies), hipMemcpyDeviceToHost));
+    uint64_t *sum = reinterpret_cast<uint64_t *>(out);
+    for (int c = C_COUNT; c < CX_END; c++) {
+        sum[c - C_COUNT] = 0;
+        for (int r = 0; r < CTR_REPLICAS; r++) sum[c - C_COUNT] += copies[r * CTR_STRIDE + c];
+    }
     return PTR_OK;
 }
 

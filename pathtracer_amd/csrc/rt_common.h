@@ -26,10 +26,16 @@ struct Pipe {
 };
 struct PassParams {
     uint64_t seed;
-    int npix, width, height;
+    int npix, width, height;       /* npix: pixels THIS pass renders (all of the film, or the tiles of this context) */
     int sample_first, sample_step; /* sample of slot = sample_first + (slot / npix) * sample_step */
     int integrator;
+    const int *pix_map;            /* pixel of the film for each pixel of the pass, or null: the same index (ptr_film_tiles) */
 };
+/* the film pixel a path slot belongs to: keys its RNG stream and places its camera ray */
+__device__ __forceinline__ int pass_pixel(const PassParams &prm, int slot) {
+    const int lp = slot % prm.npix;
+    return prm.pix_map ? prm.pix_map[lp] : lp;
+}
 
 
 /* Path and direct-light records live in HBM as planes of 32-bit words (structure of arrays):
@@ -95,7 +101,9 @@ __device__ __forceinline__ void queue_append(int *counter, int *queue, bool pred
 enum { ROUTE_NEXT = 1, ROUTE_NEE = 2, ROUTE_SHADOW = 4, ROUTE_MIS = 8 };
 
 enum { C_TOTAL = 0, C_MISS, C_SURF, C_MED, C_LIGHT, C_ZERO, C_SHADOW, C_MIS, C_PROBE, C_CAMERA, C_NODES, C_PRIMS, C_COUNT };
-static_assert(C_COUNT <= CTR_STRIDE, "a counter copy is one 128-byte line");
+/* pipeline statistics kept in the same lines, behind the PtrCounters fields (ptr_pipeline_stats_read) */
+enum { CX_FINISH_PATHS = C_COUNT, CX_FINISH_NEE, CX_SHADED, CX_NEE_RECORDS, CX_END };
+static_assert(CX_END <= CTR_STRIDE, "a counter copy is one 128-byte line");
 
 /* grid-stride helper: every lane of a wavefront runs the same number of rounds, so the ballots of
  * queue_append / ctr_flush stay convergent; n may live in device memory (written by an earlier

@@ -31,7 +31,7 @@ __global__ void __launch_bounds__(TPB) k_finish(DScene sc, Pipe pp, PassParams p
         soa_load<0, PATH_WORDS>(pp.paths, cap, slot, &ps);
         f3 ro(pp.ro[slot], pp.ro[cap + slot], pp.ro[2 * cap + slot]);
         f3 rd(pp.rd[slot], pp.rd[cap + slot], pp.rd[2 * cap + slot]);
-        Rng rng = make_rng(prm.seed, (uint32_t)(slot % prm.npix), (uint32_t)(prm.sample_first + (slot / prm.npix) * prm.sample_step));
+        Rng rng = make_rng(prm.seed, (uint32_t)pass_pixel(prm, slot), (uint32_t)(prm.sample_first + (slot / prm.npix) * prm.sample_step));
         rng.dim = (uint32_t)ps.dim;
         f3 L = ld3(ps.L), beta = ld3(ps.beta);
         int med = ps.medium, bounces = ps.bounces, pflags = ps.flags;
@@ -73,6 +73,8 @@ __global__ void __launch_bounds__(TPB) k_finish(DScene sc, Pipe pp, PassParams p
     ctr_flush(ctrs, C_ZERO, ctr.zero + nctr.zero);
     ctr_flush(ctrs, C_SHADOW, nctr.shadow);
     ctr_flush(ctrs, C_MIS, nctr.mis);
+    ctr_flush(ctrs, CX_FINISH_PATHS, ctr.total);
+    ctr_flush(ctrs, CX_FINISH_NEE, nctr.shadow + nctr.mis);
     if (SSS) ctr_flush(ctrs, C_PROBE, probes);
 }
 

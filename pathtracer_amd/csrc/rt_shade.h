@@ -22,6 +22,7 @@ k_shade(DScene sc, Pipe pp, PassParams prm, const int *n_ptr, int n_host, const 
     const SssCtx sss = {&ls, &nctr, &probes, walk != 0};
     VertexCtr ctr;
     ctr.total = ctr.miss = ctr.surf = ctr.med = ctr.light = ctr.zero = 0;
+    unsigned shaded = 0, nee_recs = 0;
     GRID_STRIDE_BEGIN(n_ptr, n_host)
     bool alive = false, want_nee = false, want_shadow = false, want_mis = false;
     int slot = 0;
@@ -33,7 +34,7 @@ k_shade(DScene sc, Pipe pp, PassParams prm, const int *n_ptr, int n_host, const 
         const NeeToPlanes rec = {reinterpret_cast<float *>(pp.nee), slot};
         f3 ro(pp.ro[slot], pp.ro[cap + slot], pp.ro[2 * cap + slot]);
         f3 rd(pp.rd[slot], pp.rd[cap + slot], pp.rd[2 * cap + slot]);
-        int pixel = slot % prm.npix;
+        int pixel = pass_pixel(prm, slot);
         int sample = prm.sample_first + (slot / prm.npix) * prm.sample_step;
         Rng rng = make_rng(prm.seed, (uint32_t)pixel, (uint32_t)sample);
         rng.dim = (uint32_t)ps.dim;
@@ -43,6 +44,8 @@ k_shade(DScene sc, Pipe pp, PassParams prm, const int *n_ptr, int n_host, const 
                                          pflags, rec, ctr, &sss, &s_lobes[threadIdx.x]);
         alive = vo.alive;
         want_nee = vo.want_nee;
+        shaded++;
+        nee_recs += want_nee ? 1 : 0;
         want_shadow = want_nee && (vo.nee_flags & NEE_A);
         want_mis = want_nee && (vo.nee_flags & NEE_B);
         if (SSS && vo.has_extra) {
@@ -73,6 +76,8 @@ k_shade(DScene sc, Pipe pp, PassParams prm, const int *n_ptr, int n_host, const 
     ctr_flush(ctrs, C_MED, ctr.med);
     ctr_flush(ctrs, C_LIGHT, ctr.light);
     ctr_flush(ctrs, C_ZERO, ctr.zero);
+    ctr_flush(ctrs, CX_SHADED, shaded);
+    ctr_flush(ctrs, CX_NEE_RECORDS, nee_recs);
     if (SSS) {
         ctr_flush(ctrs, C_SHADOW, nctr.shadow);
         ctr_flush(ctrs, C_MIS, nctr.mis);

@@ -13,6 +13,21 @@ def shard_samples(begin, ns, offset, stride):
     return range(first, begin + ns, stride)
 
 
+TILE = 8  # PTR_TILE, include/ptr_api.h
+
+
+def tile_pixels(width, height, offset, stride):
+    """Film pixel indices (row-major, y * width + x) of the 8x8 tiles t with t % stride == offset, in the order
+    ptr_film_tiles lays them out (tile by tile, rows of a tile top to bottom) - the same rule as the library's."""
+    tx, ty = (width + TILE - 1) // TILE, (height + TILE - 1) // TILE
+    out = []
+    for t in range(offset, tx * ty, stride):
+        x0, y0 = (t % tx) * TILE, (t // tx) * TILE
+        for y in range(y0, min(y0 + TILE, height)):
+            out.extend(range(y * width + x0, y * width + min(x0 + TILE, width)))
+    return out
+
+
 class DeviceArray:
     """A raw device pointer dressed up for torch.as_tensor (CUDA array interface v2)."""
 
@@ -46,9 +61,16 @@ def init_process_group(backend):
     return dist
 
 
-def all_reduce_film(dist, we, acc, samples=None):
-    """Sum the per-rank accumulators in place (every rank ends with the full film)."""
-    dist.all_reduce(we)
-    dist.all_reduce(acc)
+def all_reduce_film(dist, we, acc, samples=None, total_samples=None):
+    """Sum the per-rank accumulators in place (every rank ends with the full film): two reductions, issued together
+    (async) and waited for once.  The sample counts need no reduction when the caller knows them: after a render in
+    which every pixel received `total_samples` samples over all ranks (both the tile split and the sample split give
+    that), samples is simply filled; without total_samples it is reduced like the others."""
+    works = [dist.all_reduce(we, async_op=True), dist.all_reduce(acc, async_op=True)]
     if samples is not None:
-        dist.all_reduce(samples)
+        if total_samples is not None:
+            samples.fill_(int(total_samples))
+        else:
+            works.append(dist.all_reduce(samples, async_op=True))
+    for w in works:
+        w.wait()

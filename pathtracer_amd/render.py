@@ -66,6 +66,10 @@ class Renderer:
         capi.check(capi.hip().ptr_film_shard(self._ctx, int(offset), int(stride)))
 
     # -- render -----------------------------------------------------------------------
+    def tiles(self, offset, stride):
+        """ptr_film_tiles: this context renders the 8x8-pixel tiles t with t % stride == offset (call after film_init)."""
+        capi.check(capi.hip().ptr_film_tiles(self._ctx, int(offset), int(stride)))
+
     def render(self, ns, integrator=capi.LI_VOLPATH):
         capi.check(capi.hip().ptr_render(self._ctx, int(ns), int(integrator)))
 
@@ -149,6 +153,11 @@ class Renderer:
         c = capi.PtrCounters()
         capi.check(capi.hip().ptr_counters_read(self._ctx, C.byref(c)))
         return c.as_dict()
+
+    def pipeline_stats(self):
+        st = capi.PtrPipelineStats()
+        capi.check(capi.hip().ptr_pipeline_stats_read(self._ctx, C.byref(st)))
+        return {n: int(getattr(st, n)) for n, _ in st._fields_}
 
     def counters_reset(self):
         capi.check(capi.hip().ptr_counters_reset(self._ctx))

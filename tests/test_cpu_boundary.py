@@ -37,6 +37,20 @@ def test_library_exports_every_declared_symbol():
     assert set(declared_functions()) <= exported
 
 
+def test_multigpu_driver_loads_and_exports():
+    """host/pt_multigpu.cpp (RCCL called from C++): every entry point of pt_multigpu.h is exported; no GPU here, so creating
+    a group must fail cleanly"""
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "pathtracer_amd", "host", "pt_multigpu.h")).read(), flags=re.S)
+    names = set(re.findall(r"\b(RenderGroup[A-Za-z]+)\s*\(", hdr))
+    assert names == set(capi.MULTIGPU_SIGNATURES)
+    lib = capi.multigpu()
+    for n in names:
+        assert getattr(lib, n) is not None
+    import torch
+    if not torch.cuda.is_available():
+        assert not lib.RenderGroupCreate(1, None, 0)
+
+
 def test_every_declaration_cites_the_reference():
     """each entry point's comment names the reference file:line it replaces (or says it has none)"""
     src = open(HEADER).read()

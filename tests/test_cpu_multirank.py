@@ -44,6 +44,64 @@ def _rank(rank, world, port, out_dir):
     d.destroy_process_group()
 
 
+def _rank_tiles(rank, world, port, out_dir):
+    """tile split: each rank keeps the pixels of its 8x8 tiles (every sample of them) and zeros elsewhere"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import common
+    import pathtracer_amd as pa
+    from pathtracer_amd import dist as pdist
+
+    d = pdist.init_process_group("gloo")
+    sc = common.build("cornell_glass", W, H)
+    o = common.oracle_of(sc)
+    we, acc, smp = o.render(sc.camera, W, H, SEED, 0, NS, pa.LI_PATHSAMPLED, 1)  # per-pixel streams: a pixel's film does not depend on who else is rendered
+    mine = np.zeros(W * H, bool)
+    mine[pdist.tile_pixels(W, H, rank, world)] = True
+    we, acc, smp = we.reshape(-1, 3).copy(), acc.copy(), smp.copy()
+    we[~mine] = 0
+    acc[~mine] = 0
+    smp[~mine] = 0
+    twe, tacc, tsmp = torch.from_numpy(we), torch.from_numpy(acc), torch.from_numpy(smp)
+    pdist.all_reduce_film(d, twe, tacc, tsmp, total_samples=NS)
+    np.savez(os.path.join(out_dir, "tile_rank%d.npz" % rank), we=twe.numpy(), acc=tacc.numpy(), smp=tsmp.numpy())
+    d.barrier()
+    d.destroy_process_group()
+
+
+def test_tile_pixels_partition():
+    from pathtracer_amd.dist import tile_pixels
+
+    for w, h in ((24, 16), (37, 21), (8, 8), (5, 3), (64, 1)):
+        for world in (1, 2, 3, 8, 64):
+            parts = [tile_pixels(w, h, r, world) for r in range(world)]
+            flat = sorted(p for part in parts for p in part)
+            assert flat == list(range(w * h))  # every pixel exactly once
+            tx = (w + 7) // 8
+            for r, part in enumerate(parts):
+                for p in part:
+                    assert (((p // w) // 8) * tx + (p % w) // 8) % world == r
+
+
+def test_two_ranks_tile_split_is_bit_identical(tmp_path):
+    """the tile split sums x + 0: the reduced film equals the unsharded one bit for bit"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import common
+    import pathtracer_amd as pa
+
+    port = free_port()
+    mp.spawn(_rank_tiles, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    sc = common.build("cornell_glass", W, H)
+    o = common.oracle_of(sc)
+    we, acc, smp = o.render(sc.camera, W, H, SEED, 0, NS, pa.LI_PATHSAMPLED, 2)
+    for r in range(2):
+        g = np.load(os.path.join(str(tmp_path), "tile_rank%d.npz" % r))
+        assert np.array_equal(g["smp"], smp)
+        assert np.array_equal(g["acc"], acc)
+        assert np.array_equal(g["we"].reshape(-1), np.asarray(we).reshape(-1))
+
+
 def test_shard_samples_partition():
     from pathtracer_amd.dist import shard_samples
 

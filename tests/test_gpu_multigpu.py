@@ -1,0 +1,87 @@
+"""Multi-GPU layout on the one GPU a test box has: the tile split through the C-ABI (two contexts on one device must
+tile the film exactly - bit for bit the unsharded render), and the C++ RCCL driver (host/pt_multigpu.cpp) with a group
+of one GPU, whose reduced film must be the single-context film."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import pathtracer_amd as pa
+from pathtracer_amd import dist as pdist
+
+import common
+
+pytestmark = pytest.mark.gpu
+SEED, NS = 9, 5
+
+
+def _render(sc, w, h, tiles=None, shard=None, integ=pa.LI_PATHSAMPLED):
+    with pa.Renderer(0) as r:
+        r.upload(sc)
+        r.set_camera(sc.camera)
+        r.film_init(w, h, SEED)
+        if tiles:
+            r.tiles(*tiles)
+        if shard:
+            r.shard(*shard)
+        r.render(NS, integ)
+        r.sync()
+        return [a.copy() for a in r.film()]
+
+
+@pytest.mark.parametrize("size", [(32, 24), (37, 21)])
+@pytest.mark.parametrize("world", [2, 3])
+def test_tile_shards_tile_the_film(cuda, size, world):
+    w, h = size
+    sc = common.build("cornell_glass", w, h)
+    full = _render(sc, w, h)
+    parts = [_render(sc, w, h, tiles=(k, world)) for k in range(world)]
+    for k, (we, acc, smp) in enumerate(parts):
+        mine = np.zeros(w * h, bool)
+        mine[pdist.tile_pixels(w, h, k, world)] = True
+        assert (smp.reshape(-1)[mine] == NS).all() and (smp.reshape(-1)[~mine] == 0).all()  # its own tiles and nothing else
+        assert not we.reshape(-1, 3)[~mine].any() and not acc.reshape(-1)[~mine].any()
+    for i in range(3):
+        total = parts[0][i].copy()
+        for p in parts[1:]:
+            total += p[i]
+        assert np.array_equal(total, full[i])  # x + 0 = x: bit for bit the unsharded film
+
+
+def test_tiles_combine_with_sample_shards(cuda):
+    w, h = 32, 24
+    sc = common.build("cornell", w, h)
+    full = _render(sc, w, h)
+    parts = [_render(sc, w, h, tiles=(t, 2), shard=(s, 2)) for t in range(2) for s in range(2)]
+    smp = sum(p[2] for p in parts)
+    assert (smp == NS).all()
+    acc = sum(p[1] for p in parts)
+    assert np.allclose(acc, full[1], rtol=1e-12)
+    we = sum(p[0].astype(np.float64) for p in parts)
+    assert np.allclose(we, full[0], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("split", [0, 1])
+def test_render_group_of_one_gpu(cuda, split):
+    """libpt_multigpu.so: ncclCommInitAll + the grouped all-reduce, with one GPU in the group"""
+    w, h = 48, 32
+    sc = common.build("zoo", w, h)
+    full = _render(sc, w, h, integ=pa.LI_VOLPATH)
+    m = pa.capi.multigpu()
+    g = m.RenderGroupCreate(1, None, split)
+    assert g, m.RenderGroupLastError()
+    try:
+        assert m.RenderGroupSize(g) == 1
+        C.CDLL(None).srand(1)  # the scene build draws from libc rand() like Aggregator::Wrap; Renderer.upload reseeds the same way
+        for rc in (m.RenderGroupUpload(g, sc.flat), m.RenderGroupCamera(g, C.byref(sc.camera)), m.RenderGroupFilmInit(g, w, h, SEED),
+                   m.RenderGroupRenderSamples(g, NS, pa.LI_VOLPATH), m.RenderGroupReduce(g)):
+            assert rc == 0, m.RenderGroupLastError()
+        we = np.zeros((w * h, 3), np.float32)
+        acc = np.zeros(w * h, np.float64)
+        smp = np.zeros(w * h, np.int64)
+        assert m.RenderGroupFilmRead(g, we.ctypes.data, acc.ctypes.data, smp.ctypes.data) == 0, m.RenderGroupLastError()
+    finally:
+        m.RenderGroupFree(g)
+    assert np.array_equal(smp, full[2].reshape(-1))
+    assert np.array_equal(acc, full[1].reshape(-1))
+    assert np.array_equal(we.reshape(-1), full[0].reshape(-1))
