@@ -275,8 +275,8 @@ int ptr_film_tiles(PtrContext *ctx, int tile_offset, int tile_stride);
 /* Replaces Render<<<blocks,threads>>>(image, scene, camera, ns) (main.cpp:421-457,1139):
  * ns more samples for every pixel with integrator PTR_LI_*.  Asynchronous, and ordered with the
  * context's stream (ptr_set_stream; default: the null stream) on both sides: the passes run on internal
- * streams that first wait for everything queued on the context's stream before this call, and work
- * queued on the context's stream after this call waits for the passes. */
+ * streams; they read and write the film (their last kernel) only after everything queued on the context's stream
+ * before this call, and work queued on the context's stream after this call waits for the passes. */
 int ptr_render(PtrContext *ctx, int ns, int integrator);
 /* Replaces cudaDeviceAssert() after a launch (main.cpp:1140). */
 int ptr_sync(PtrContext *ctx);

@@ -27,7 +27,20 @@ def test_top_level_keys():
     assert b["vs_baseline"] is None  # BASELINE.md holds no published number for this metric
     assert b["data"] == "synthetic" and b["dtype"] == "f32"
     assert "workload" in b["config"] and "model" not in b["config"]
-    assert b["value"] > 0 and abs(b["ms_per_step"] * b["steps"] * 1e-3 * b["value"] * 1e6 / (b["samples_per_s"] * b["rays_per_sample"] * b["ms_per_step"] * b["steps"] * 1e-3) - 1) < 1e-6
+    # value = incoherent rays (depth >= 1) per second; the coherent camera rays are reported beside it
+    assert b["value"] > 0 and abs(b["value"] - (b["mrays_secondary_closest"] + b["mrays_secondary_any"])) < 1e-6 * b["value"]
+    assert abs(b["mrays_all"] - (b["value"] + b["mrays_primary"])) < 1e-6 * b["mrays_all"]
+    assert abs(b["mrays_all"] * 1e6 / (b["samples_per_s"] * b["rays_per_sample"]) - 1) < 1e-6
+    assert abs(b["mrays_primary"] * 1e6 / b["samples_per_s"] - 1) < 1e-6
+
+
+def test_shade_roofline_object():
+    r = newest_line()["roofline_shade"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "bytes_per_vertex", "vertices_per_launch", "avg_launch_ms"):
+        assert k in r, k
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert 192.0 <= r["bytes_per_vertex"] <= 384.0
+    assert abs(r["achieved"] - r["bytes_per_vertex"] * r["vertices_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
 
 
 def test_roofline_object():

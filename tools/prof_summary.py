@@ -1,5 +1,5 @@
 """Condense rocprofv3 CSV output (kernel trace / counter collection) into a per-kernel table.
-usage: python tools/prof_summary.py [--json out.json] <dir> [<dir> ...] > profiles/<name>.txt
+usage: python tools/prof_summary.py [--json out.json] [--config N] <dir> [<dir> ...] > profiles/<name>.txt
 --json also writes {kernel: {calls, avg_ns, counters: {name: sum}, dispatches}} for bench.py's roofline.traffic."""
 import csv
 import glob
@@ -16,8 +16,12 @@ def short(name):
 
 args = sys.argv[1:]
 json_out = None
-if args and args[0] == "--json":
-    json_out = args[1]
+config = None
+while args and args[0] in ("--json", "--config"):
+    if args[0] == "--json":
+        json_out = args[1]
+    else:
+        config = int(args[1])
     args = args[2:]
 summary = defaultdict(lambda: {"counters": {}})
 for d in args:
@@ -41,4 +45,7 @@ for d in args:
             summary[k]["counters"].update(acc[k])
             summary[k]["dispatches"] = len(calls[k])
 if json_out:
-    json.dump(summary, open(json_out, "w"), indent=1, sort_keys=True)
+    out = dict(summary)
+    if config is not None:
+        out["_config"] = config  # which bench.py --config the passes ran (bench.py only prices a kernel with traffic of its own config)
+    json.dump(out, open(json_out, "w"), indent=1, sort_keys=True)
