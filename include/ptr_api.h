@@ -338,6 +338,39 @@ int ptr_trace_closest_noalloc(PtrContext *ctx, int n, const float *d_o, const fl
 int ptr_trace_occluded(PtrContext *ctx, int n, const float *d_o, const float *d_d,
                        const float *d_tmax, int32_t *d_occluded);
 
+/* ---- unit hooks for the known-answer tests (no counterpart: the reference has no tests) ------------
+ * The building blocks of the shade stage on plain device arrays of n records (`in_width` floats in, `out_width` floats
+ * out per record), so that tests can integrate, histogram and compare them with closed forms:
+ *   kind                      in                                out          reference
+ *   PTR_UNIT_FR_DIELECTRIC    cosI etaI etaT                    F            material.cpp:5-30
+ *   PTR_UNIT_FR_CONDUCTOR     cosI etaI(3) etaT(3) k(3)         F(3)         material.cpp:32-52
+ *   PTR_UNIT_GGX_D            ax ay wh(3)                       D            microfacet.cpp:3-21
+ *   PTR_UNIT_GGX_G1           ax ay w(3)                        G1           microfacet.h:30-36
+ *   PTR_UNIT_GGX_PDF          ax ay wo(3) wh(3)                 pdf          microfacet.cpp (Pdf, visible normals)
+ *   PTR_UNIT_GGX_SAMPLE_WH    ax ay wo(3) u(2)                  wh(3)        microfacet.cpp:23-120
+ *   PTR_UNIT_HG_P             cosTheta g                        p            medium.cpp:4-19
+ *   PTR_UNIT_HG_SAMPLE        g wo(3) u(2)                      wi(3) p      medium.cpp:21-64
+ *   PTR_UNIT_ROUGH_TO_ALPHA   roughness                         alpha        microfacet.h:38-43
+ *   PTR_UNIT_ENV_SAMPLE       u(2)                              uv(2) pdf    sampling.h:49-77 (the scene's light map)
+ *   PTR_UNIT_ENV_PDF          uv(2)                             pdf          sampling.h:63-69
+ *   PTR_UNIT_SSS_SR           r                                 Sr(3)        bssrdf.cpp:383-411 (material of `prim`)
+ *   PTR_UNIT_SSS_PDF_SR       ch r                              pdf          bssrdf.cpp:413-437
+ *   PTR_UNIT_SSS_SAMPLE_SR    ch u                              r            bssrdf.cpp:439-445
+ * Asynchronous on the context's stream. */
+enum {
+    PTR_UNIT_FR_DIELECTRIC = 0, PTR_UNIT_FR_CONDUCTOR, PTR_UNIT_GGX_D, PTR_UNIT_GGX_G1, PTR_UNIT_GGX_PDF, PTR_UNIT_GGX_SAMPLE_WH,
+    PTR_UNIT_HG_P, PTR_UNIT_HG_SAMPLE, PTR_UNIT_ROUGH_TO_ALPHA, PTR_UNIT_ENV_SAMPLE, PTR_UNIT_ENV_PDF, PTR_UNIT_SSS_SR,
+    PTR_UNIT_SSS_PDF_SR, PTR_UNIT_SSS_SAMPLE_SR, PTR_UNIT_KINDS
+};
+int ptr_unit_eval(PtrContext *ctx, int prim, int kind, int n, const float *d_in, int in_width, float *d_out, int out_width);
+/* BSDF::f and BSDF::Pdf over the non-specular lobes (sample = 0: d_wi_or_u holds n directions wi; d_wi_out / d_flags unused)
+ * or BSDF::Sample_f over all lobes (sample = 1: d_wi_or_u holds n pairs u; wi, f, pdf and the sampled lobe's type flags
+ * come back) of the material of primitive `prim` (ComputeScatteringFunctions, material.cpp:103-165 ->
+ * reflection.cpp:591-701) at a canonical interaction: p = 0, n = +z, dpdu = +x, uv from d_uv[2n].  World-space
+ * directions wo[3n] (AoS).  No counterpart in the reference.  Asynchronous on the context's stream. */
+int ptr_unit_bsdf(PtrContext *ctx, int prim, int sample, int n, const float *d_wo, const float *d_wi_or_u, const float *d_uv,
+                  float *d_wi_out, float *d_f, float *d_pdf, int32_t *d_flags);
+
 /* ---- introspection (no counterpart) ----------------------------------------------- */
 int ptr_profile_enable(PtrContext *ctx, int on);
 int ptr_profile_reset(PtrContext *ctx);

@@ -35,6 +35,9 @@ def lib():
         L.orc_glibc_rand.argtypes = [C.c_int]
         L.orc_rng_draw.restype = C.c_float
         L.orc_rng_draw.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.orc_bsdf_eval.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5
+        L.orc_bsdf_sample.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7
+        L.orc_unit_eval.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.orc_film_rgb8.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p]
         _lib = L
     return _lib
@@ -113,6 +116,46 @@ class OracleScene:
         a, b = C.c_int64(), C.c_int64()
         lib().orc_bvh_info(self._h, C.byref(a), C.byref(b))
         return {"nodes": a.value, "handles": b.value}
+
+
+# unit hooks (orc_api.cpp orc_unit_eval; pathtracer_amd.Renderer.unit_eval is the device twin): kind -> (id, in width, out width)
+UNIT_KINDS = {"fr_dielectric": (0, 3, 1), "fr_conductor": (1, 10, 3), "ggx_d": (2, 5, 1), "ggx_g1": (3, 5, 1), "ggx_pdf": (4, 8, 1),
+              "ggx_sample_wh": (5, 7, 3), "hg_p": (6, 2, 1), "hg_sample": (7, 6, 4), "rough_to_alpha": (8, 1, 1), "env_sample": (9, 2, 3),
+              "env_pdf": (10, 2, 1), "sss_sr": (11, 1, 3), "sss_pdf_sr": (12, 2, 1), "sss_sample_sr": (13, 2, 1)}
+
+
+def unit_eval(kind, rows, scene=None, prim=-1):
+    """rows: [n, in width] float32 -> [n, out width]; scene: an OracleScene for the env_* / sss_* kinds"""
+    kid, iw, ow = UNIT_KINDS[kind]
+    a = np.ascontiguousarray(rows, dtype=np.float32).reshape(-1, iw)
+    out = np.zeros((a.shape[0], ow), np.float32)
+    rc = lib().orc_unit_eval(scene._h if scene is not None else None, int(prim), kid, a.shape[0], a.ctypes.data, iw, out.ctypes.data, ow)
+    if rc:
+        raise ValueError("orc_unit_eval(%s) failed" % kind)
+    return out
+
+
+def bsdf_eval(scene, prim, wo, wi, uv=None):
+    """f and pdf (non-specular lobes) of primitive `prim`'s material at a canonical interaction (n = +z, dpdu = +x)"""
+    wo = np.ascontiguousarray(wo, dtype=np.float32).reshape(-1, 3)
+    wi = np.ascontiguousarray(wi, dtype=np.float32).reshape(-1, 3)
+    n = wo.shape[0]
+    uv = np.full((n, 2), 0.5, np.float32) if uv is None else np.ascontiguousarray(uv, dtype=np.float32).reshape(-1, 2)
+    f, pdf = np.zeros((n, 3), np.float32), np.zeros(n, np.float32)
+    lib().orc_bsdf_eval(scene._h, int(prim), n, wo.ctypes.data, wi.ctypes.data, uv.ctypes.data, f.ctypes.data, pdf.ctypes.data)
+    return f, pdf
+
+
+def bsdf_sample(scene, prim, wo, u2, uv=None):
+    """BSDF::Sample_f(BSDF_ALL): wi, f, pdf, sampled type flags"""
+    wo = np.ascontiguousarray(wo, dtype=np.float32).reshape(-1, 3)
+    u2 = np.ascontiguousarray(u2, dtype=np.float32).reshape(-1, 2)
+    n = wo.shape[0]
+    uv = np.full((n, 2), 0.5, np.float32) if uv is None else np.ascontiguousarray(uv, dtype=np.float32).reshape(-1, 2)
+    wi, f, pdf, fl = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32), np.zeros(n, np.float32), np.zeros(n, np.int32)
+    lib().orc_bsdf_sample(scene._h, int(prim), n, wo.ctypes.data, u2.ctypes.data, uv.ctypes.data, wi.ctypes.data, f.ctypes.data,
+                          pdf.ctypes.data, fl.ctypes.data)
+    return wi, f, pdf, fl
 
 
 def image_of(we, acc):

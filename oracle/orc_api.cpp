@@ -478,4 +478,54 @@ int orc_bsdf_sample(void *h, int prim, int n, const float *wo, const float *u2, 
     return 0;
 }
 
+/* ---- unit hooks: scalar building blocks, n records of `in`, results to `out` (widths per kind below) ----
+ *  kind 0 fr_dielectric   in: cosI etaI etaT                      out: F
+ *  kind 1 fr_conductor    in: cosI etaI(3) etaT(3) k(3)           out: F(3)
+ *  kind 2 ggx_d           in: ax ay wh(3)                         out: D
+ *  kind 3 ggx_g1          in: ax ay w(3)                          out: G1
+ *  kind 4 ggx_pdf         in: ax ay wo(3) wh(3)                   out: pdf
+ *  kind 5 ggx_sample_wh   in: ax ay wo(3) u(2)                    out: wh(3)
+ *  kind 6 hg_p            in: cosTheta g                          out: p
+ *  kind 7 hg_sample       in: g wo(3) u(2)                        out: wi(3) p
+ *  kind 8 rough_to_alpha  in: roughness                           out: alpha
+ *  kind 9 env_sample      in: u(2)               (scene h)        out: uv(2) pdf
+ *  kind 10 env_pdf        in: uv(2)              (scene h)        out: pdf
+ *  kind 11 sss_sr         in: r                  (scene h, prim)  out: Sr(3)
+ *  kind 12 sss_pdf_sr     in: ch r               (scene h, prim)  out: pdf
+ *  kind 13 sss_sample_sr  in: ch u               (scene h, prim)  out: r
+ * Returns 0, or -1 for an unknown kind / missing scene part. */
+int orc_unit_eval(void *h, int prim, int kind, int n, const float *in, int in_w, float *out, int out_w) {
+    OrcScene *os = (OrcScene *)h;
+    BSDF sss_bsdf(unit_si(prim < 0 ? 0 : prim, 0.5f, 0.5f));
+    if (kind >= 9 && !os) return -1;
+    if (kind == 9 || kind == 10) { if (os->sc.env.func.empty()) return -1; }
+    if (kind >= 11) {
+        SurfaceInteraction si = unit_si(prim, 0.5f, 0.5f);
+        ComputeScatteringFunctions(os->sc, &si, &sss_bsdf);
+        if (!sss_bsdf.has_bssrdf) return -1;
+    }
+    for (int i = 0; i < n; i++) {
+        const float *a = in + (size_t)i * in_w;
+        float *o = out + (size_t)i * out_w;
+        switch (kind) {
+        case 0: o[0] = Unit_FrDielectric(a[0], a[1], a[2]); break;
+        case 1: { V3 r = Unit_FrConductor(a[0], V3(a[1], a[2], a[3]), V3(a[4], a[5], a[6]), V3(a[7], a[8], a[9])); o[0] = r.x; o[1] = r.y; o[2] = r.z; } break;
+        case 2: o[0] = Unit_GGX_D(a[0], a[1], V3(a[2], a[3], a[4])); break;
+        case 3: o[0] = Unit_GGX_G1(a[0], a[1], V3(a[2], a[3], a[4])); break;
+        case 4: o[0] = Unit_GGX_Pdf(a[0], a[1], V3(a[2], a[3], a[4]), V3(a[5], a[6], a[7])); break;
+        case 5: { V3 r = Unit_GGX_Sample_wh(a[0], a[1], V3(a[2], a[3], a[4]), V2(a[5], a[6])); o[0] = r.x; o[1] = r.y; o[2] = r.z; } break;
+        case 6: o[0] = Unit_HG(a[0], a[1]); break;
+        case 7: { PhaseFunction ph; ph.g = a[0]; V3 wi; Float p = PhaseSample_p(ph, V3(a[1], a[2], a[3]), &wi, V2(a[4], a[5])); o[0] = wi.x; o[1] = wi.y; o[2] = wi.z; o[3] = p; } break;
+        case 8: o[0] = RoughnessToAlpha(a[0]); break;
+        case 9: { Float pdf = 0; V2 uv = Unit_D2_Sample(os->sc.env, V2(a[0], a[1]), &pdf); o[0] = uv[0]; o[1] = uv[1]; o[2] = pdf; } break;
+        case 10: o[0] = Unit_D2_Pdf(os->sc.env, V2(a[0], a[1])); break;
+        case 11: { V3 r = Unit_Sr(sss_bsdf.bssrdf, a[0]); o[0] = r.x; o[1] = r.y; o[2] = r.z; } break;
+        case 12: o[0] = Unit_Pdf_Sr(sss_bsdf.bssrdf, (int)a[0], a[1]); break;
+        case 13: o[0] = Unit_Sample_Sr(sss_bsdf.bssrdf, (int)a[0], a[1]); break;
+        default: return -1;
+        }
+    }
+    return 0;
+}
+
 } /* extern "C" */

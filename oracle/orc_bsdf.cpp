@@ -603,4 +603,13 @@ void ComputeScatteringFunctions(const Scene &sc, SurfaceInteraction *si, BSDF *b
     }
 }
 
+/* ---- unit hooks (tests only) ---- */
+Float Unit_FrDielectric(Float cosI, Float etaI, Float etaT) { return FrDieletric(cosI, etaI, etaT); }
+V3 Unit_FrConductor(Float cosI, const V3 &etaI, const V3 &etaT, const V3 &k) { return FrConductor(cosI, etaI, etaT, k); }
+static MicrofacetDistribution unit_dist(Float ax, Float ay) { MicrofacetDistribution m; m.alphax = ax; m.alphay = ay; m.sampleVisibleArea = true; return m; }
+Float Unit_GGX_D(Float ax, Float ay, const V3 &wh) { return MF_D(unit_dist(ax, ay), wh); }
+Float Unit_GGX_G1(Float ax, Float ay, const V3 &w) { return MF_G1(unit_dist(ax, ay), w); }
+Float Unit_GGX_Pdf(Float ax, Float ay, const V3 &wo, const V3 &wh) { return MF_Pdf(unit_dist(ax, ay), wo, wh); }
+V3 Unit_GGX_Sample_wh(Float ax, Float ay, const V3 &wo, const V2 &u) { return MF_Sample_wh(unit_dist(ax, ay), wo, u); }
+
 } // namespace orc

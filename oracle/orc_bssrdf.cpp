@@ -363,4 +363,9 @@ V3 BSSRDF_Sample_S(const Scene &sc, const SeparableBSSRDF &b, BSDF *bsdf, Float 
     return Sp;
 }
 
+/* ---- unit hooks (tests only) ---- */
+V3 Unit_Sr(const SeparableBSSRDF &b, Float r) { return Tabulated_Sr(b, r); }
+Float Unit_Pdf_Sr(const SeparableBSSRDF &b, int ch, Float r) { return Tabulated_Pdf_Sr(b, ch, r); }
+Float Unit_Sample_Sr(const SeparableBSSRDF &b, int ch, Float u) { return Tabulated_Sample_Sr(b, ch, u); }
+
 } // namespace orc

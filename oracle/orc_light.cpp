@@ -270,4 +270,9 @@ V3 UniformSampleOneLight(const Scene &sc, const Interaction &it, const BSDF *bsd
     return EstimateDirect(sc, it, bsdf, phase, uScattering, lightNum, uLight, handleMedium) / lightPdf;
 }
 
+/* ---- unit hooks (tests only) ---- */
+Float Unit_HG(Float cosTheta, Float g) { return PhaseHG(cosTheta, g); }
+V2 Unit_D2_Sample(const EnvMap &e, const V2 &u, Float *pdf) { return D2_SampleContinuous(e, u, pdf); }
+Float Unit_D2_Pdf(const EnvMap &e, const V2 &p) { return D2_Pdf(e, p); }
+
 } // namespace orc

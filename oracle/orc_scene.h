@@ -294,6 +294,21 @@ V3 MediumSample(const Scene &sc, int medium, const Ray &ray, const V2 &u, Medium
 Float PhaseSample_p(const PhaseFunction &ph, const V3 &wo, V3 *wi, const V2 &u);
 Float PhaseP(const PhaseFunction &ph, const V3 &wo, const V3 &wi);
 
+/* ---- unit hooks (tests only): the building blocks the known-answer tests integrate, histogram and compare with
+ * closed forms (tests/test_cpu_pins.py); thin non-static doors onto the file-local functions ---- */
+Float Unit_FrDielectric(Float cosI, Float etaI, Float etaT);
+V3 Unit_FrConductor(Float cosI, const V3 &etaI, const V3 &etaT, const V3 &k);
+Float Unit_GGX_D(Float ax, Float ay, const V3 &wh);
+Float Unit_GGX_G1(Float ax, Float ay, const V3 &w);
+Float Unit_GGX_Pdf(Float ax, Float ay, const V3 &wo, const V3 &wh);
+V3 Unit_GGX_Sample_wh(Float ax, Float ay, const V3 &wo, const V2 &u);
+Float Unit_HG(Float cosTheta, Float g);
+V2 Unit_D2_Sample(const EnvMap &e, const V2 &u, Float *pdf);
+Float Unit_D2_Pdf(const EnvMap &e, const V2 &p);
+V3 Unit_Sr(const SeparableBSSRDF &b, Float r);
+Float Unit_Pdf_Sr(const SeparableBSSRDF &b, int ch, Float r);
+Float Unit_Sample_Sr(const SeparableBSSRDF &b, int ch, Float u);
+
 /* ---- orc_render.cpp ---- */
 struct Camera { V3 position, lower_left, horizontal, vertical, u, v, w; Float lensRadius; };
 struct RNG { /* counter-based stand-in for cuRAND (see DESIGN.md "RNG") */

@@ -125,6 +125,8 @@ HIP_SIGNATURES = {
     "ptr_trace_closest_noalloc": (C.c_int, [CTX, C.c_int] + [C.c_void_p] * 8),
     "ptr_trace_occluded": (C.c_int, [CTX, C.c_int] + [C.c_void_p] * 4),
     "ptr_pipeline_stats_read": (C.c_int, [CTX, C.POINTER(PtrPipelineStats)]),
+    "ptr_unit_eval": (C.c_int, [CTX, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "ptr_unit_bsdf": (C.c_int, [CTX, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7),
     "ptr_profile_enable": (C.c_int, [CTX, C.c_int]),
     "ptr_profile_reset": (C.c_int, [CTX]),
     "ptr_profile_read": (C.c_int, [CTX, C.POINTER(PtrKernelProfile), C.c_int, C.POINTER(C.c_int)]),

@@ -1322,6 +1322,40 @@ int ptr_trace_occluded(PtrContext *ctx, int n, const float *d_o, const float *d_
     return api_trace(ctx, soa_io(n, nullptr, n, d_o, d_d, d_tmax, d_occluded, nullptr, nullptr, nullptr, nullptr), true);
 }
 
+/* ---- unit hooks (rt_unit.hip) ---- */
+static const int kUnitWidths[PTR_UNIT_KINDS][2] = {{3, 1}, {10, 3}, {5, 1}, {5, 1}, {8, 1}, {7, 3}, {2, 1}, {6, 4}, {1, 1}, {2, 3}, {2, 1}, {1, 3}, {2, 1}, {2, 1}};
+int ptr_unit_eval(PtrContext *ctx, int prim, int kind, int n, const float *d_in, int in_width, float *d_out, int out_width) {
+    int rc = ctx_use(ctx);
+    if (rc) return rc;
+    if (kind < 0 || kind >= PTR_UNIT_KINDS) return set_err(PTR_ERR_INVALID, "unknown unit kind");
+    if (in_width != kUnitWidths[kind][0] || out_width != kUnitWidths[kind][1]) return set_err(PTR_ERR_INVALID, "record widths do not match the kind");
+    if (n < 0 || (n > 0 && (!d_in || !d_out))) return set_err(PTR_ERR_INVALID, "bad record arrays");
+    if (kind >= PTR_UNIT_ENV_SAMPLE) {
+        if (!ctx->has_scene) return set_err(PTR_ERR_STATE, "this kind needs a scene");
+        if (kind <= PTR_UNIT_ENV_PDF && !ctx->sc.has_env) return set_err(PTR_ERR_STATE, "the scene has no light map");
+        if (kind >= PTR_UNIT_SSS_SR) {
+            if (prim < 0 || prim >= ctx->sc.n_prims) return set_err(PTR_ERR_INVALID, "primitive index out of range");
+            if (!ctx->scene_has_sss) return set_err(PTR_ERR_STATE, "the scene has no subsurface material");
+        }
+    }
+    if (n == 0) return PTR_OK;
+    rt_launch_unit(ctx->stream, ctx->sc, prim, kind, n, d_in, in_width, d_out, out_width);
+    HIPCHK(hipGetLastError());
+    return PTR_OK;
+}
+int ptr_unit_bsdf(PtrContext *ctx, int prim, int sample, int n, const float *d_wo, const float *d_wi_or_u, const float *d_uv, float *d_wi_out, float *d_f,
+                  float *d_pdf, int32_t *d_flags) {
+    int rc = ctx_use(ctx);
+    if (rc) return rc;
+    if (!ctx->has_scene) return set_err(PTR_ERR_STATE, "no scene uploaded");
+    if (prim < 0 || prim >= ctx->sc.n_prims) return set_err(PTR_ERR_INVALID, "primitive index out of range");
+    if (n < 0 || (n > 0 && (!d_wo || !d_wi_or_u || !d_uv || !d_f || !d_pdf || (sample && (!d_wi_out || !d_flags))))) return set_err(PTR_ERR_INVALID, "bad arrays");
+    if (n == 0) return PTR_OK;
+    rt_launch_unit_bsdf(ctx->stream, ctx->sc, prim, sample ? 1 : 0, n, d_wo, d_wi_or_u, d_uv, d_wi_out, d_f, d_pdf, d_flags);
+    HIPCHK(hipGetLastError());
+    return PTR_OK;
+}
+
 /* on: bit 0 = time every launch with HIP events, bit 1 = count child boxes / leaf items tested */
 int ptr_profile_enable(PtrContext *ctx, int on) {
     if (!ctx) return set_err(PTR_ERR_INVALID, "null context");

@@ -157,3 +157,7 @@ void rt_launch_qtrace2any(unsigned blocks, hipStream_t s, const DScene &sc, cons
 void rt_launch_qtrace3(bool count, unsigned blocks, hipStream_t s, const DScene &sc, const TraceIO &path, const TraceIO &shadow, const TraceIO &mis,
                        unsigned long long *ctrs);
 void rt_launch_qtrace(bool any, bool count, unsigned blocks, hipStream_t s, const DScene &sc, const TraceIO &io, unsigned long long *ctrs);
+/* unit hooks (rt_unit.hip) */
+void rt_launch_unit(hipStream_t s, const DScene &sc, int prim, int kind, int n, const float *in, int in_w, float *out, int out_w);
+void rt_launch_unit_bsdf(hipStream_t s, const DScene &sc, int prim, int sample, int n, const float *wo, const float *wi_or_u, const float *uv, float *wi_out,
+                         float *f, float *pdf, int *flags);

@@ -148,6 +148,46 @@ class Renderer:
     def trace_occluded(self, n, d_o, d_d, d_tmax, d_occ):
         capi.check(capi.hip().ptr_trace_occluded(self._ctx, int(n), d_o, d_d, d_tmax, d_occ))
 
+    # -- unit hooks (known-answer tests) ------------------------------------------------
+    UNIT_KINDS = {"fr_dielectric": (0, 3, 1), "fr_conductor": (1, 10, 3), "ggx_d": (2, 5, 1), "ggx_g1": (3, 5, 1), "ggx_pdf": (4, 8, 1),
+                  "ggx_sample_wh": (5, 7, 3), "hg_p": (6, 2, 1), "hg_sample": (7, 6, 4), "rough_to_alpha": (8, 1, 1), "env_sample": (9, 2, 3),
+                  "env_pdf": (10, 2, 1), "sss_sr": (11, 1, 3), "sss_pdf_sr": (12, 2, 1), "sss_sample_sr": (13, 2, 1)}
+
+    def unit_eval(self, kind, rows, prim=-1):
+        """ptr_unit_eval over host rows [n, in width] -> numpy [n, out width] (copies through torch tensors on this device)"""
+        import numpy as np
+        import torch
+
+        kid, iw, ow = self.UNIT_KINDS[kind]
+        a = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.float32).reshape(-1, iw)).cuda()
+        out = torch.zeros((a.shape[0], ow), dtype=torch.float32, device=a.device)
+        torch.cuda.synchronize()
+        capi.check(capi.hip().ptr_unit_eval(self._ctx, int(prim), kid, a.shape[0], a.data_ptr(), iw, out.data_ptr(), ow))
+        self.sync()
+        return out.cpu().numpy()
+
+    def unit_bsdf(self, prim, wo, wi=None, u2=None, uv=None):
+        """ptr_unit_bsdf: (f, pdf) for directions wi, or (wi, f, pdf, flags) for sample pairs u2"""
+        import numpy as np
+        import torch
+
+        two = torch.from_numpy(np.ascontiguousarray(wo, dtype=np.float32).reshape(-1, 3)).cuda()
+        n = two.shape[0]
+        tuv = torch.from_numpy(np.full((n, 2), 0.5, np.float32) if uv is None else np.ascontiguousarray(uv, dtype=np.float32).reshape(-1, 2)).cuda()
+        f = torch.zeros((n, 3), dtype=torch.float32, device=two.device)
+        pdf = torch.zeros(n, dtype=torch.float32, device=two.device)
+        wout = torch.zeros((n, 3), dtype=torch.float32, device=two.device)
+        fl = torch.zeros(n, dtype=torch.int32, device=two.device)
+        sample = wi is None
+        x = torch.from_numpy(np.ascontiguousarray(u2 if sample else wi, dtype=np.float32).reshape(n, -1)).cuda()
+        torch.cuda.synchronize()
+        capi.check(capi.hip().ptr_unit_bsdf(self._ctx, int(prim), 1 if sample else 0, n, two.data_ptr(), x.data_ptr(), tuv.data_ptr(), wout.data_ptr(),
+                                            f.data_ptr(), pdf.data_ptr(), fl.data_ptr()))
+        self.sync()
+        if sample:
+            return wout.cpu().numpy(), f.cpu().numpy(), pdf.cpu().numpy(), fl.cpu().numpy()
+        return f.cpu().numpy(), pdf.cpu().numpy()
+
     # -- introspection ----------------------------------------------------------------
     def counters(self):
         c = capi.PtrCounters()
