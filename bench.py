@@ -121,6 +121,7 @@ def main():
     ap.add_argument("--size", type=int, default=0, help="scene size parameter (config 1: knot tessellation, 2 * s * s triangles)")
     ap.add_argument("--variant", type=int, default=-1, help="config 1: 0 rough glass, 1 plastic, 2 specular glass, 3 matte")
     ap.add_argument("--integrator", type=int, default=3)
+    ap.add_argument("--bvh", choices=["host", "device"], default="host", help="geometry BVH builder: host binned SAH, or the device LBVH (SURVEY 8f row 3)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--roofline-only", action="store_true",
@@ -159,9 +160,11 @@ def main():
     # the shade stage's own kernels; otherwise they go through the persistent tracer
     walks = args.integrator == 3 and any(fs.primitives[i].no_mat or fs.primitives[i].mat.is_emissive for i in range(fs.n_primitives))
     r = pa.Renderer(local_rank)
+    pa.set_bvh_build_mode(args.bvh)
     t_up = time.time()
     r.upload(scene)
     t_up = time.time() - t_up
+    bvh_build = r.bvh_build_info()
     r.set_camera(scene.camera)
 
     def new_film():
@@ -294,7 +297,8 @@ def main():
                                    (label, W, H, spp, "per GPU" if args.scaling == "weak" else "in total", args.integrator),
                        "config_index": args.config, "triangles": n_tris, "particles": n_parts, "primitives": fs.n_primitives,
                        "width": W, "height": H, "bvh_nodes": bvh["nodes"], "bvh_items": bvh["items"], "bvh_bytes": bvh["bytes"],
-                       "scene_upload_s": round(t_up, 3),
+                       "scene_upload_s": round(t_up, 3), "bvh_builder": bvh_build["builder"], "bvh_build_ms": round(bvh_build["build_ms"], 3),
+                       "bvh_depth": bvh_build["depth"],
                        "parallelism": "%s over %d GPU(s), scene replicated, one all-reduce of the accumulators" %
                                       ("8x8-pixel tiles round-robin" if split == "tiles" else "samples round-robin", world)},
             "value_definition": "scene queries of depth >= 1 (path segments after the camera ray + shadow + MIS + BSSRDF probe rays) per second; camera rays excluded",

@@ -253,6 +253,27 @@ typedef struct PtrBuiltScene PtrBuiltScene;
 int ptr_scene_build(const PtrFlatScene *scene, PtrBuiltScene **out);
 int ptr_scene_upload_built(PtrContext *ctx, const PtrBuiltScene *built);
 int ptr_scene_built_free(PtrBuiltScene *built);
+/* Who builds the geometry BVHs (one per mesh / particle cloud) inside ptr_scene_build / ptr_scene_upload, process-wide:
+ *   PTR_BVH_HOST_SAH     binned SAH on the host (default)
+ *   PTR_BVH_DEVICE_LBVH  linear BVH on the current HIP device (Morton codes, radix sort, Karras hierarchy, refit, collapse
+ *                        to the same 4-wide nodes): for geometry that changes per frame (SPH clouds), where the reference's
+ *                        host _CreateBVH (primitive.cpp:537-582: 14 s for 7 M triangles) is the bottleneck.  SURVEY 8f row 3.
+ * Environment PTR_BVH_BUILD=device selects the second at start-up.  Traces give the same hits with either tree (hits at
+ * bit-equal t aside); traversal cost differs. */
+#define PTR_BVH_HOST_SAH 0
+#define PTR_BVH_DEVICE_LBVH 1
+int ptr_scene_build_mode(int mode);
+/* builder of the uploaded scene's geometry trees, the time it took for all of them (host wall time for SAH, device time for
+ * LBVH) and the depth of the deepest 4-wide tree (no counterpart; the reference prints its build time, primitive.cpp:607-615) */
+typedef struct PtrBvhBuildInfo {
+    int32_t builder, depth;
+    double build_ms;
+    /* surface-area estimate for the largest geometry tree, per ray through its root box: child boxes tested, leaf items
+     * tested, leaves entered (a build-time figure of merit; bench.py measures the real per-ray counts) */
+    double sah_boxes, sah_items, sah_leaves;
+} PtrBvhBuildInfo;
+int ptr_bvh_build_info(PtrContext *ctx, PtrBvhBuildInfo *out);
+int ptr_scene_built_info(const PtrBuiltScene *built, PtrBvhBuildInfo *out); /* the same of a scene not uploaded yet */
 /* Replaces Camera::Config's writes into the managed Camera (camera.cpp:145-197). */
 int ptr_camera_set(PtrContext *ctx, const PtrCamera *cam);
 

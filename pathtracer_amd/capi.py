@@ -93,6 +93,11 @@ class PtrPipelineStats(C.Structure):
     _fields_ = [(n, u64) for n in ("finish_paths", "finish_nee_rays", "shaded_vertices", "nee_records")]
 
 
+class PtrBvhBuildInfo(C.Structure):
+    _fields_ = [("builder", C.c_int32), ("depth", C.c_int32), ("build_ms", C.c_double), ("sah_boxes", C.c_double), ("sah_items", C.c_double),
+                ("sah_leaves", C.c_double)]
+
+
 class PtrKernelProfile(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("launches", u64), ("total_ms", C.c_double), ("items", u64)]
 
@@ -105,6 +110,9 @@ HIP_SIGNATURES = {
     "ptr_last_error": (C.c_char_p, []),
     "ptr_set_stream": (C.c_int, [CTX, C.c_void_p]),
     "ptr_scene_upload": (C.c_int, [CTX, C.POINTER(PtrFlatScene)]),
+    "ptr_scene_build_mode": (C.c_int, [C.c_int]),
+    "ptr_bvh_build_info": (C.c_int, [CTX, C.POINTER(PtrBvhBuildInfo)]),
+    "ptr_scene_built_info": (C.c_int, [C.c_void_p, C.POINTER(PtrBvhBuildInfo)]),
     "ptr_scene_build": (C.c_int, [C.POINTER(PtrFlatScene), C.POINTER(C.c_void_p)]),
     "ptr_scene_upload_built": (C.c_int, [CTX, C.c_void_p]),
     "ptr_scene_built_free": (C.c_int, [C.c_void_p]),
@@ -230,6 +238,11 @@ def multigpu():
             raise RuntimeError("pathtracer_amd: %s is missing - build it with `make -C pathtracer_amd`" % MULTIGPU_LIB)
         _multigpu = _bind(C.CDLL(MULTIGPU_LIB), MULTIGPU_SIGNATURES)
     return _multigpu
+
+
+def bvh_build_info_dict(o):
+    return {"builder": "device_lbvh" if o.builder == 1 else "host_sah", "build_ms": o.build_ms, "depth": o.depth, "sah_boxes": o.sah_boxes,
+            "sah_items": o.sah_items, "sah_leaves": o.sah_leaves}
 
 
 class PtrError(RuntimeError):

@@ -12,6 +12,7 @@
  * kernels start from bit-identical inputs; the acceleration structure itself is new.
  */
 #include "ptr_host.h"
+#include <chrono>
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -38,7 +39,9 @@ struct Box {
     float mn[3], mx[3];
     void reset() { for (int i = 0; i < 3; i++) { mn[i] = FLT_MAX; mx[i] = -FLT_MAX; } }
     void grow(const float *p) { for (int i = 0; i < 3; i++) { if (p[i] < mn[i]) mn[i] = p[i]; if (p[i] > mx[i]) mx[i] = p[i]; } }
-    void grow(const Box &b) { grow(b.mn); grow(b.mx); }
+    void grow(const Box &b) { /* an empty box (reset) adds nothing */
+        for (int i = 0; i < 3; i++) { if (b.mn[i] < mn[i]) mn[i] = b.mn[i]; if (b.mx[i] > mx[i]) mx[i] = b.mx[i]; }
+    }
     float half_area() const {
         float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
         if (dx < 0 || dy < 0 || dz < 0) return 0;
@@ -341,6 +344,16 @@ int fail(std::string *err, int code, const std::string &msg) {
 
 } // namespace
 
+static int g_bvh_mode = -1;
+int ptr_bvh_build_mode_get() {
+    if (g_bvh_mode < 0) {
+        const char *e = getenv("PTR_BVH_BUILD");
+        g_bvh_mode = (e && !strcmp(e, "device")) ? PTR_BVH_DEVICE_LBVH : PTR_BVH_HOST_SAH;
+    }
+    return g_bvh_mode;
+}
+void ptr_bvh_build_mode_set(int mode) { g_bvh_mode = mode == PTR_BVH_DEVICE_LBVH ? PTR_BVH_DEVICE_LBVH : PTR_BVH_HOST_SAH; }
+
 int ptr_flatten(const PtrFlatScene *fs, HostScene *hs, std::string *err) {
     if (!fs || !hs) return fail(err, PTR_ERR_INVALID, "null scene");
     if (fs->n_primitives < 0 || fs->n_meshes < 0 || fs->n_clouds < 0 || fs->n_images < 0)
@@ -402,9 +415,24 @@ int ptr_flatten(const PtrFlatScene *fs, HostScene *hs, std::string *err) {
     /* one SAH BVH per mesh and per particle cloud, all in the same node / item arrays */
     std::vector<int32_t> mesh_root(hs->meshes.size(), BVH_NO_CHILD), cloud_root(hs->clouds.size(), BVH_NO_CHILD);
     std::vector<Box> mesh_box(hs->meshes.size()), cloud_box(hs->clouds.size());
-    auto build_geom = [&](const std::vector<Box> &boxes, const std::vector<Item48> &raw, int32_t *root, Box *bound) -> int {
+    hs->bvh_builder = ptr_bvh_build_mode_get();
+    auto build_geom_inner = [&](const std::vector<Box> &boxes, const std::vector<Item48> &raw, int32_t *root, Box *bound) -> int {
         if (boxes.empty()) return PTR_OK;
         if (hs->items.size() + boxes.size() >= (1u << 27)) return fail(err, PTR_ERR_LIMIT, "more than 2^27 BVH items");
+        if (hs->bvh_builder == PTR_BVH_DEVICE_LBVH) { /* linear BVH on the current device, same tables (rt_build.hip) */
+            static_assert(sizeof(Box) == 6 * sizeof(float), "Box is six floats");
+            int depth = 0;
+            double ms = 0;
+            std::string gerr;
+            int rc = ptr_gpu_build_geom(reinterpret_cast<const float *>(boxes.data()), raw.data(), boxes.size(), &hs->nodes, &hs->items, root, bound->mn, &depth, &ms,
+                                        &gerr);
+            if (rc) return fail(err, rc, gerr);
+            hs->bvh_build_ms += ms;
+            if (3 * (depth + 1) + 24 > BVH_STACK) return fail(err, PTR_ERR_LIMIT, "BVH deeper than the traversal stack");
+            if (depth > hs->bvh_depth) hs->bvh_depth = depth;
+            return PTR_OK;
+        }
+        const auto t_begin = std::chrono::steady_clock::now();
         Builder b(boxes, 0, hs->items.size());
         b.nodes.reserve(boxes.size());
         b.order.reserve(boxes.size());
@@ -416,7 +444,36 @@ int ptr_flatten(const PtrFlatScene *fs, HostScene *hs, std::string *err) {
         if (3 * (c.max_depth + 1) + 24 > BVH_STACK) return fail(err, PTR_ERR_LIMIT, "BVH deeper than the traversal stack");
         if (c.max_depth > hs->bvh_depth) hs->bvh_depth = c.max_depth;
         for (size_t i = 0; i < b.order.size(); i++) hs->items.push_back(raw[b.order[i]]);
+        hs->bvh_build_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
         return PTR_OK;
+    };
+    auto build_geom = [&](const std::vector<Box> &boxes, const std::vector<Item48> &raw, int32_t *root, Box *bound) -> int {
+        int rc = build_geom_inner(boxes, raw, root, bound);
+        if (rc || boxes.size() <= hs->sah_of_items || *root < 0) return rc;
+        /* expected work per ray through the root box (uniform random lines: P(child | root) = area ratio) */
+        hs->sah_of_items = boxes.size();
+        hs->sah_boxes = hs->sah_items = hs->sah_leaves = 0;
+        const float root_area = bound->half_area();
+        if (!(root_area > 0)) return rc;
+        std::vector<std::pair<int32_t, double>> todo{{*root, 1.0}};
+        while (!todo.empty()) {
+            const std::pair<int32_t, double> cur = todo.back();
+            todo.pop_back();
+            const Node128 &nd = hs->nodes[cur.first];
+            for (int i = 0; i < 4; i++) {
+                if (nd.c[i].ref == BVH_NO_CHILD) continue;
+                hs->sah_boxes += cur.second;
+                Box cb;
+                for (int a = 0; a < 3; a++) { cb.mn[a] = nd.c[i].mn[a]; cb.mx[a] = nd.c[i].mx[a]; }
+                const double p = cb.half_area() / root_area;
+                if (nd.c[i].ref >= 0) todo.push_back({nd.c[i].ref, p});
+                else {
+                    hs->sah_leaves += p;
+                    hs->sah_items += p * ((((uint32_t)(-(nd.c[i].ref + 1))) >> 27) + 1);
+                }
+            }
+        }
+        return rc;
     };
     for (size_t mi = 0; mi < hs->meshes.size(); mi++) {
         const HostMesh &hm = hs->meshes[mi];

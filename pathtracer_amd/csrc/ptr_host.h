@@ -51,7 +51,20 @@ struct HostScene {
     int view_medium = -1, has_env = 0;
     int bvh_depth = 0;
     bool has_media = false;
+    int bvh_builder = 0;     /* PTR_BVH_HOST_SAH / PTR_BVH_DEVICE_LBVH: who built the geometry trees */
+    double bvh_build_ms = 0; /* all geometry trees: host wall time (SAH) or device time (LBVH) */
+    /* surface-area estimate of the traversal cost of the largest geometry tree, per ray that enters its root box:
+     * child boxes tested, leaf items tested, leaves entered */
+    double sah_boxes = 0, sah_items = 0, sah_leaves = 0;
+    size_t sah_of_items = 0;
 };
+
+/* geometry BVH of one mesh / particle cloud on the current device (rt_build.hip) */
+int ptr_gpu_build_geom(const float *boxes6, const Item48 *raw, size_t n_items, std::vector<Node128> *nodes, std::vector<Item48> *items, int32_t *root,
+                       float *bound6, int *depth, double *ms, std::string *err);
+/* which builder ptr_flatten uses (ptr_scene_build_mode / environment PTR_BVH_BUILD=device) */
+int ptr_bvh_build_mode_get();
+void ptr_bvh_build_mode_set(int mode);
 
 /* returns PTR_OK or an error code with *err filled */
 /* photon-beam-diffusion profile table of a subsurface material (ptr_tables.cpp) */

@@ -357,6 +357,7 @@ struct PtrContext {
     long long quad_below = 3000000;
     DCamera cam;
     int64_t bvh_bytes = 0;
+    PtrBvhBuildInfo bvh_build = {};
     /* film */
     int width = 0, height = 0, npix = 0;
     uint64_t seed = 0;
@@ -852,6 +853,16 @@ int ptr_set_stream(PtrContext *ctx, void *hip_stream) {
 struct PtrBuiltScene {
     HostScene hs;
 };
+static PtrBvhBuildInfo built_info(const HostScene &hs) {
+    PtrBvhBuildInfo o = {};
+    o.builder = hs.bvh_builder;
+    o.depth = hs.bvh_depth;
+    o.build_ms = hs.bvh_build_ms;
+    o.sah_boxes = hs.sah_boxes;
+    o.sah_items = hs.sah_items;
+    o.sah_leaves = hs.sah_leaves;
+    return o;
+}
 
 int ptr_scene_build(const PtrFlatScene *scene, PtrBuiltScene **out) {
     if (!out) return set_err(PTR_ERR_INVALID, "null out pointer");
@@ -866,14 +877,31 @@ int ptr_scene_build(const PtrFlatScene *scene, PtrBuiltScene **out) {
     *out = b;
     return PTR_OK;
 }
+int ptr_scene_build_mode(int mode) {
+    if (mode != PTR_BVH_HOST_SAH && mode != PTR_BVH_DEVICE_LBVH) return set_err(PTR_ERR_INVALID, "unknown BVH build mode");
+    ptr_bvh_build_mode_set(mode);
+    return PTR_OK;
+}
+int ptr_bvh_build_info(PtrContext *ctx, PtrBvhBuildInfo *out) {
+    if (!ctx || !out) return set_err(PTR_ERR_INVALID, "null argument");
+    if (!ctx->has_scene) return set_err(PTR_ERR_STATE, "no scene uploaded");
+    *out = ctx->bvh_build;
+    return PTR_OK;
+}
+int ptr_scene_built_info(const PtrBuiltScene *built, PtrBvhBuildInfo *out) {
+    if (!built || !out) return set_err(PTR_ERR_INVALID, "null argument");
+    *out = built_info(built->hs);
+    return PTR_OK;
+}
 int ptr_scene_built_free(PtrBuiltScene *built) {
     delete built;
     return PTR_OK;
 }
 int ptr_scene_upload(PtrContext *ctx, const PtrFlatScene *scene) {
-    if (!ctx) return set_err(PTR_ERR_INVALID, "null context");
+    int rc = ctx_use(ctx); /* a device build (ptr_scene_build_mode) runs on this context's GPU */
+    if (rc) return rc;
     PtrBuiltScene *b = nullptr;
-    int rc = ptr_scene_build(scene, &b);
+    rc = ptr_scene_build(scene, &b);
     if (rc) return rc;
     rc = ptr_scene_upload_built(ctx, b);
     ptr_scene_built_free(b);
@@ -953,6 +981,7 @@ int ptr_scene_upload_built(PtrContext *ctx, const PtrBuiltScene *built) {
     sc.has_env = hs.has_env;
     ctx->sc = sc;
     ctx->bvh_bytes = (int64_t)(hs.nodes.size() * sizeof(Node128) + hs.items.size() * sizeof(Item48));
+    ctx->bvh_build = built_info(hs);
     ctx->scene_has_media = hs.has_media;
     ctx->scene_has_sss = !hs.tables.empty();
     ctx->scene_all_opaque = true;

@@ -9,6 +9,12 @@ import numpy as np
 from . import capi
 
 
+def set_bvh_build_mode(mode):
+    """'host' (binned SAH, default) or 'device' (LBVH built on the current GPU): who builds the geometry BVHs of the
+    scenes uploaded from now on (ptr_scene_build_mode, process-wide)."""
+    capi.check(capi.hip().ptr_scene_build_mode({"host": 0, "device": 1}[mode]))
+
+
 class Renderer:
     def __init__(self, device=-1):
         self._ctx = capi.CTX()
@@ -214,6 +220,11 @@ class Renderer:
         capi.check(capi.hip().ptr_profile_read(self._ctx, arr, capi.PROF_KERNELS, C.byref(n)))
         return {arr[i].name.decode(): {"launches": int(arr[i].launches), "total_ms": float(arr[i].total_ms), "items": int(arr[i].items)}
                 for i in range(n.value)}
+
+    def bvh_build_info(self):
+        o = capi.PtrBvhBuildInfo()
+        capi.check(capi.hip().ptr_bvh_build_info(self._ctx, C.byref(o)))
+        return capi.bvh_build_info_dict(o)
 
     def bvh_info(self):
         a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
