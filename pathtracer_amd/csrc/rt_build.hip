@@ -14,8 +14,9 @@
  *   5. k_refit         leaves to root, the second arrival at a node (atomic flag) unions its children's boxes
  *   6. k_collapse      breadth first, one launch per level of the 4-wide tree: a work item (binary node -> wide node)
  *                      opens the child of largest area until four slots are taken (the host collapser's rule); a
- *                      subtree of at most BVH_MAX_LEAF items becomes a leaf - its items are contiguous, so the leaf
- *                      ref is (first, count) - anything larger gets a wide node of its own and goes to the next level
+ *                      subtree of at most BVH_MAX_LEAF items becomes a leaf when the host builder's SAH rule says so
+ *                      (makes_leaf) - its items are contiguous, so the leaf ref is (first, count) - anything else
+ *                      gets a wide node of its own and goes to the next level
  *   7. k_gather_items  Item48 records in sorted order
  *
  * Every step is a streaming or gather kernel over N items: HBM-bound; the sort dominates.  The tree is a linear BVH:
@@ -166,6 +167,21 @@ __device__ __forceinline__ float half_area(const GBox &b) {
 __device__ __forceinline__ int ref_count(const BinTree &t, int ref) { return ref >= 0 ? t.last[ref] - t.first[ref] + 1 : 1; }
 __device__ __forceinline__ int ref_first(const BinTree &t, int ref) { return ref >= 0 ? t.first[ref] : ~ref; }
 
+/* Does the subtree under ref become one leaf?  Up to two items: always.  Three or four: by the host builder's rule
+ * (ptr_build.cpp): a leaf unless testing the two halves separately is expected to be cheaper,
+ * n > 1 + (A_l n_l + A_r n_r) / A - which it is for items that overlap little, not for a cluster of particle spheres */
+__device__ __forceinline__ bool makes_leaf(const BinTree &t, const GBox *boxes, const unsigned long long *keys, int ref, const GBox &box) {
+    if (ref < 0) return true;
+    const int n = ref_count(t, ref);
+    if (n > BVH_MAX_LEAF) return false;
+    if (n <= 2) return true;
+    const int l = t.left[ref], r = t.right[ref];
+    const float a = half_area(box);
+    if (!(a > 0.f)) return true;
+    const float split = 1.f + (half_area(ref_box(t, boxes, keys, l)) * ref_count(t, l) + half_area(ref_box(t, boxes, keys, r)) * ref_count(t, r)) / a;
+    return (float)n <= split;
+}
+
 /* 6. one level of the 4-wide tree.  work[k] = (binary inner node, wide node index) */
 __global__ void __launch_bounds__(TPB) k_collapse(const GBox *boxes, const unsigned long long *keys, BinTree t, const int2 *work, int n_work, int2 *next, int *n_next,
                                                   int *n_wide, Node128 *out, int node_base, unsigned item_base) {
@@ -174,16 +190,19 @@ __global__ void __launch_bounds__(TPB) k_collapse(const GBox *boxes, const unsig
     const int bin = work[k].x, me = work[k].y;
     int refs[4];
     GBox bx[4];
+    bool leaf[4];
     int ns = 2;
     refs[0] = t.left[bin];
     refs[1] = t.right[bin];
-    bx[0] = ref_box(t, boxes, keys, refs[0]);
-    bx[1] = ref_box(t, boxes, keys, refs[1]);
-    while (ns < 4) { /* open the inner child of largest area (a subtree that fits a leaf stays closed) */
+    for (int i = 0; i < 2; i++) {
+        bx[i] = ref_box(t, boxes, keys, refs[i]);
+        leaf[i] = makes_leaf(t, boxes, keys, refs[i], bx[i]);
+    }
+    while (ns < 4) { /* open the child of largest area that does not become a leaf */
         int pick = -1;
         float area = -1.f;
         for (int i = 0; i < ns; i++)
-            if (refs[i] >= 0 && ref_count(t, refs[i]) > BVH_MAX_LEAF) {
+            if (!leaf[i]) {
                 const float a = half_area(bx[i]);
                 if (a > area) { area = a; pick = i; }
             }
@@ -191,8 +210,10 @@ __global__ void __launch_bounds__(TPB) k_collapse(const GBox *boxes, const unsig
         const int l = t.left[refs[pick]], r = t.right[refs[pick]];
         refs[pick] = l;
         bx[pick] = ref_box(t, boxes, keys, l);
+        leaf[pick] = makes_leaf(t, boxes, keys, l, bx[pick]);
         refs[ns] = r;
         bx[ns] = ref_box(t, boxes, keys, r);
+        leaf[ns] = makes_leaf(t, boxes, keys, r, bx[ns]);
         ns++;
     }
     Node128 nd;
@@ -200,7 +221,7 @@ __global__ void __launch_bounds__(TPB) k_collapse(const GBox *boxes, const unsig
         if (i < ns) {
             const int cnt = ref_count(t, refs[i]);
             int ref;
-            if (cnt <= BVH_MAX_LEAF) {
+            if (leaf[i]) {
                 const unsigned packed = (item_base + (unsigned)ref_first(t, refs[i])) | ((unsigned)(cnt - 1) << 27);
                 ref = -(int)packed - 1;
             } else {
@@ -309,7 +330,7 @@ int ptr_gpu_build_geom(const float *boxes6, const Item48 *raw, size_t n_items, s
             GCHK(hipMalloc((void **)&d_work[0], sizeof(int2) * n));
             GCHK(hipMalloc((void **)&d_work[1], sizeof(int2) * n));
             GCHK(hipMalloc((void **)&d_counts, 3 * sizeof(int)));
-            if (n <= BVH_MAX_LEAF) {
+            if (n <= 2) {
                 *root = -(int32_t)(item_base | ((unsigned)(n - 1) << 27)) - 1; /* the whole geometry is one leaf */
             } else {
                 const int2 first_work = make_int2(0, 0);
