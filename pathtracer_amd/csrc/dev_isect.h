@@ -82,10 +82,8 @@ PD bool slab_minmax(float mnx, float mny, float mnz, float mxx, float mxy, float
         const int rl_ = sw_ ? rb : ra, rh_ = sw_ ? ra : rb;   \
         ta = tl_; tb = th_; ra = rl_; rb = rh_;          \
     } while (0)
-PD int bvh4_visit(const Node128 *nodes, int node, const f3 &ro, const f3 &inv, float tmax, int &r0, int &r1, int &r2, int &r3, unsigned *tested) {
-    const float4 *np = reinterpret_cast<const float4 *>(nodes + node);
-    /* child i = np[2 i] (min xyz, max x), np[2 i + 1] (max y, max z, ref, -) */
-    const float4 a0 = np[0], b0 = np[1], a1 = np[2], b1 = np[3], a2 = np[4], b2 = np[5], a3 = np[6], b3 = np[7];
+PD int bvh4_visit_loaded(const float4 &a0, const float4 &b0, const float4 &a1, const float4 &b1, const float4 &a2, const float4 &b2, const float4 &a3,
+                         const float4 &b3, const f3 &ro, const f3 &inv, float tmax, int &r0, int &r1, int &r2, int &r3, unsigned *tested) {
     r0 = __float_as_int(b0.z); r1 = __float_as_int(b1.z); r2 = __float_as_int(b2.z); r3 = __float_as_int(b3.z);
     float t0 = kInfinity, t1 = kInfinity, t2 = kInfinity, t3 = kInfinity;
     if (tested) *tested += (r0 != BVH_NO_CHILD) + (r1 != BVH_NO_CHILD) + (r2 != BVH_NO_CHILD) + (r3 != BVH_NO_CHILD);
@@ -105,6 +103,43 @@ PD int bvh4_visit(const Node128 *nodes, int node, const f3 &ro, const f3 &inv, f
     BVH4_CSWAP(t1, r1, t3, r3);
     BVH4_CSWAP(t1, r1, t2, r2);
     return (r0 != BVH_NO_CHILD) + (r1 != BVH_NO_CHILD) + (r2 != BVH_NO_CHILD) + (r3 != BVH_NO_CHILD);
+}
+PD int bvh4_visit(const Node128 *nodes, int node, const f3 &ro, const f3 &inv, float tmax, int &r0, int &r1, int &r2, int &r3, unsigned *tested) {
+    const float4 *np = reinterpret_cast<const float4 *>(nodes + node);
+    /* child i = np[2 i] (min xyz, max x), np[2 i + 1] (max y, max z, ref, -) */
+    const float4 a0 = np[0], b0 = np[1], a1 = np[2], b1 = np[3], a2 = np[4], b2 = np[5], a3 = np[6], b3 = np[7];
+    return bvh4_visit_loaded(a0, b0, a1, b1, a2, b2, a3, b3, ro, inv, tmax, r0, r1, r2, r3, tested);
+}
+/* The same with nodes[0 .. PT_LDS_TOP) - the upper levels of every geometry tree (BVH_NODE_PREFIX, ptr_build.cpp) - read
+ * from the block's LDS copy instead: rows of 9 float4, so that lanes on different nodes spread over the banks */
+#ifndef PT_LDS_TOP
+#define PT_LDS_TOP 0
+#endif
+#define PT_LDS_ROW 9
+PD int bvh4_visit_staged(const Node128 *nodes, const float4 *staged, int node, const f3 &ro, const f3 &inv, float tmax, int &r0, int &r1, int &r2, int &r3,
+                         unsigned *tested) {
+#if PT_LDS_TOP > 0
+    float4 a0, b0, a1, b1, a2, b2, a3, b3;
+    if (node < PT_LDS_TOP) {
+        const float4 *lp = staged + node * PT_LDS_ROW;
+        a0 = lp[0]; b0 = lp[1]; a1 = lp[2]; b1 = lp[3]; a2 = lp[4]; b2 = lp[5]; a3 = lp[6]; b3 = lp[7];
+    } else {
+        const float4 *np = reinterpret_cast<const float4 *>(nodes + node);
+        a0 = np[0]; b0 = np[1]; a1 = np[2]; b1 = np[3]; a2 = np[4]; b2 = np[5]; a3 = np[6]; b3 = np[7];
+    }
+    return bvh4_visit_loaded(a0, b0, a1, b1, a2, b2, a3, b3, ro, inv, tmax, r0, r1, r2, r3, tested);
+#else
+    return bvh4_visit(nodes, node, ro, inv, tmax, r0, r1, r2, r3, tested);
+#endif
+}
+/* block-wide copy of the staged nodes; every thread of the block calls it once, before the first visit */
+PD void bvh4_stage(const DScene &sc, float4 *staged) {
+#if PT_LDS_TOP > 0
+    const int ns = sc.n_nodes < PT_LDS_TOP ? sc.n_nodes : PT_LDS_TOP;
+    const float4 *src = reinterpret_cast<const float4 *>(sc.nodes);
+    for (int i = threadIdx.x; i < ns * 8; i += blockDim.x) staged[(i >> 3) * PT_LDS_ROW + (i & 7)] = src[i];
+    __syncthreads();
+#endif
 }
 
 /* ---- triangle, mesh.cpp:162-249 (watertight test, double fallback for zero edge functions) ----

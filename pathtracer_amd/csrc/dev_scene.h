@@ -37,6 +37,7 @@ struct TopNode {
 };
 #define TOP_STACK 48
 #define BVH_NO_CHILD INT32_MIN
+#define BVH_NODE_PREFIX 64 /* nodes[0 .. 64): the upper levels of all geometry trees, breadth first (ptr_build.cpp) */
 #define BVH_MAX_LEAF 4
 #define BVH_STACK 96 /* entries per lane: up to 3 pushes per level of a 4-wide tree */
 

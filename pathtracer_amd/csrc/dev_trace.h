@@ -194,7 +194,7 @@ static __device__ unsigned long long g_pt_stats[PS_N];
 #endif
 
 template <class Source, bool COUNT>
-PD void persistent_trace(const DScene &sc, Source src, int *lds, unsigned *total_nodes, unsigned *total_items) {
+PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *staged, unsigned *total_nodes, unsigned *total_items) {
     int ovf[OVF_STACK];
 #ifdef PT_STATS
     unsigned long long st_[PS_N] = {};
@@ -337,7 +337,7 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, unsigned *total
         while (mode == TM_GEOM && node >= 0) {
             PS_WAVE_IT(PS_IN_IT, PS_IN_LANES);
             int r0, r1, r2, r3;
-            const int nh = bvh4_visit(sc.nodes, node, ro, inv, tmax, r0, r1, r2, r3, COUNT ? &rn : nullptr);
+            const int nh = bvh4_visit_staged(sc.nodes, staged, node, ro, inv, tmax, r0, r1, r2, r3, COUNT ? &rn : nullptr);
             if (nh == 0) {
                 if (sp == sp_base) mode = TM_TOPLEAF;
                 else node = PT_POP();
@@ -436,7 +436,7 @@ enum { TS_IDLE = 0, TS_TOP = 1, TS_TOPLEAF = 2, TS_IN = 3, TS_LEAF = 4 };
 #define PT_HYST 0
 #endif
 template <class Source, bool COUNT>
-PD void persistent_trace_sched(const DScene &sc, Source src, int *lds, unsigned *total_nodes, unsigned *total_items) {
+PD void persistent_trace_sched(const DScene &sc, Source src, int *lds, const float4 *staged, unsigned *total_nodes, unsigned *total_items) {
     int ovf[OVF_STACK];
     const int lane = __lane_id();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -551,7 +551,7 @@ PD void persistent_trace_sched(const DScene &sc, Source src, int *lds, unsigned 
             if (mode == TS_IN) {
                 PS_WAVE_IT(PS_IN_IT, PS_IN_LANES);
                 int r0, r1, r2, r3;
-                const int nh = bvh4_visit(sc.nodes, node, ro, inv, tmax, r0, r1, r2, r3, COUNT ? &rn : nullptr);
+                const int nh = bvh4_visit_staged(sc.nodes, staged, node, ro, inv, tmax, r0, r1, r2, r3, COUNT ? &rn : nullptr);
                 if (nh == 0) PT_GEOM_NEXT();
                 else {
                     if (sp + 3 <= LDS_STACK) { /* the usual case: three unconditional LDS stores, farthest child deepest */
@@ -681,10 +681,10 @@ PD void persistent_trace_sched(const DScene &sc, Source src, int *lds, unsigned 
 #define PT_SCHED 0 /* r02 on config[1]: phases in sequence 190.5 ms per 32-spp pass, fullest-phase-first 193.2 */
 #endif
 template <class Source, bool COUNT>
-PD void persistent_trace_any(const DScene &sc, Source src, int *lds, unsigned *total_nodes, unsigned *total_items) {
+PD void persistent_trace_any(const DScene &sc, Source src, int *lds, const float4 *staged, unsigned *total_nodes, unsigned *total_items) {
 #if PT_SCHED
-    persistent_trace_sched<Source, COUNT>(sc, src, lds, total_nodes, total_items);
+    persistent_trace_sched<Source, COUNT>(sc, src, lds, staged, total_nodes, total_items);
 #else
-    persistent_trace<Source, COUNT>(sc, src, lds, total_nodes, total_items);
+    persistent_trace<Source, COUNT>(sc, src, lds, staged, total_nodes, total_items);
 #endif
 }

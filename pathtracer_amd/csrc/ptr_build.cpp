@@ -519,6 +519,39 @@ int ptr_flatten(const PtrFlatScene *fs, HostScene *hs, std::string *err) {
         if (rc) return rc;
     }
 
+    /* The upper levels of all geometry trees first in nodes[] (breadth first, the trees taking turns), the rest in the
+     * order the builder left them: the tracer can keep nodes[0 .. NODE_PREFIX) in LDS (dev_trace.h, PT_LDS_TOP), and the
+     * nodes every ray starts with share a few cache lines either way. */
+    {
+        const size_t nn = hs->nodes.size();
+        std::vector<int32_t> order; /* new index -> old index, the prefix */
+        std::vector<int32_t> queue;
+        for (int32_t r : mesh_root) if (r >= 0) queue.push_back(r);
+        for (int32_t r : cloud_root) if (r >= 0) queue.push_back(r);
+        for (size_t head = 0; head < queue.size() && order.size() < (size_t)BVH_NODE_PREFIX; head++) {
+            const int32_t cur = queue[head];
+            order.push_back(cur);
+            for (int i = 0; i < 4; i++) {
+                const int32_t ref = hs->nodes[cur].c[i].ref;
+                if (ref >= 0 && ref != BVH_NO_CHILD) queue.push_back(ref);
+            }
+        }
+        std::vector<int32_t> new_of(nn, -1);
+        for (size_t k = 0; k < order.size(); k++) new_of[order[k]] = (int32_t)k;
+        int32_t next = (int32_t)order.size();
+        for (size_t i = 0; i < nn; i++) if (new_of[i] < 0) new_of[i] = next++;
+        std::vector<Node128> moved(nn);
+        for (size_t i = 0; i < nn; i++) {
+            Node128 nd = hs->nodes[i];
+            for (int k = 0; k < 4; k++)
+                if (nd.c[k].ref >= 0) nd.c[k].ref = new_of[nd.c[k].ref];
+            moved[new_of[i]] = nd;
+        }
+        hs->nodes.swap(moved);
+        for (int32_t &r : mesh_root) if (r >= 0) r = new_of[r];
+        for (int32_t &r : cloud_root) if (r >= 0) r = new_of[r];
+    }
+
     if (fs->camera_medium.is_valid) {
         hs->view_medium = (int)hs->media.size();
         hs->media.push_back(conv_medium(fs->camera_medium));

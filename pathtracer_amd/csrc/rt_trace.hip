@@ -5,13 +5,22 @@
 
 /* Aggregator::Intersect (ANY = false) / VisibilityTester::Unoccluded (ANY = true) over a queue of
  * rays: persistent wavefronts, see dev_trace.h */
+/* nodes[0 .. PT_LDS_TOP) in LDS (dev_isect.h bvh4_visit_staged); PT_LDS_TOP = 0: nothing staged, no LDS taken */
+#if PT_LDS_TOP > 0
+#define PT_STAGED_NODES(sc)                                  \
+    __shared__ float4 s_staged[PT_LDS_TOP * PT_LDS_ROW];     \
+    bvh4_stage(sc, s_staged)
+#else
+#define PT_STAGED_NODES(sc) const float4 *s_staged = nullptr
+#endif
 template <bool ANY, bool COUNT>
 __global__ void __launch_bounds__(TRACE_TPB) __attribute__((amdgpu_waves_per_eu(PT_WAVES, PT_WAVES))) k_ptrace(DScene sc, TraceIO io, unsigned long long *ctrs) {
     __shared__ int s_stack[LDS_STACK * TRACE_TPB];
+    PT_STAGED_NODES(sc);
     unsigned tn = 0, ti = 0;
     OneSource<ANY> src;
     src.io = io;
-    persistent_trace_any<OneSource<ANY>, COUNT>(sc, src, &s_stack[threadIdx.x], &tn, &ti);
+    persistent_trace_any<OneSource<ANY>, COUNT>(sc, src, &s_stack[threadIdx.x], s_staged, &tn, &ti);
     if (COUNT) {
         ctr_flush(ctrs, C_NODES, tn);
         ctr_flush(ctrs, C_PRIMS, ti);
@@ -23,12 +32,13 @@ template <bool COUNT>
 __global__ void __launch_bounds__(TRACE_TPB) __attribute__((amdgpu_waves_per_eu(PT_WAVES, PT_WAVES)))
 k_ptrace3(DScene sc, TraceIO path, TraceIO shadow, TraceIO mis, unsigned long long *ctrs) {
     __shared__ int s_stack[LDS_STACK * TRACE_TPB];
+    PT_STAGED_NODES(sc);
     unsigned tn = 0, ti = 0;
     ThreeSources src;
     src.path = path;
     src.shadow = shadow;
     src.mis = mis;
-    persistent_trace_any<ThreeSources, COUNT>(sc, src, &s_stack[threadIdx.x], &tn, &ti);
+    persistent_trace_any<ThreeSources, COUNT>(sc, src, &s_stack[threadIdx.x], s_staged, &tn, &ti);
     if (COUNT) {
         ctr_flush(ctrs, C_NODES, tn);
         ctr_flush(ctrs, C_PRIMS, ti);
@@ -37,11 +47,12 @@ k_ptrace3(DScene sc, TraceIO path, TraceIO shadow, TraceIO mis, unsigned long lo
 
 __global__ void __launch_bounds__(TRACE_TPB) __attribute__((amdgpu_waves_per_eu(PT_WAVES, PT_WAVES))) k_ptrace2any(DScene sc, TraceIO a, TraceIO b) {
     __shared__ int s_stack[LDS_STACK * TRACE_TPB];
+    PT_STAGED_NODES(sc);
     unsigned tn = 0, ti = 0;
     TwoAny src;
     src.a = a;
     src.b = b;
-    persistent_trace_any<TwoAny, false>(sc, src, &s_stack[threadIdx.x], &tn, &ti);
+    persistent_trace_any<TwoAny, false>(sc, src, &s_stack[threadIdx.x], s_staged, &tn, &ti);
 }
 void rt_launch_ptrace2any(unsigned blocks, hipStream_t s, const DScene &sc, const TraceIO &a, const TraceIO &b) {
     hipLaunchKernelGGL(k_ptrace2any, dim3(blocks), dim3(TRACE_TPB), 0, s, sc, a, b);
