@@ -253,6 +253,16 @@ typedef struct PtrBuiltScene PtrBuiltScene;
 int ptr_scene_build(const PtrFlatScene *scene, PtrBuiltScene **out);
 int ptr_scene_upload_built(PtrContext *ctx, const PtrBuiltScene *built);
 int ptr_scene_built_free(PtrBuiltScene *built);
+/* The light-map tables of PtrEnvMap built on the device: replaces BuildSpectrumMipMap (texture.cpp:111-215: scale, Lanczos
+ * resample to powers of two, pyramid), the func table of texture.cpp:235-252 and CreateDistribution2D (infinite.cpp:7-39)
+ * as InsertEXRLightMap runs them on the host (scene.cpp:703-719).  rgb: 3*width*height floats as read from the file,
+ * rows top-down; scale3: the Spectrum the pixels are multiplied by.  The tables are the floats the host pipeline gives,
+ * bit for bit (csrc/rt_envmap.hip says how).  ptr_envmap_view points a PtrEnvMap at them (light_to_world is left alone);
+ * they live until ptr_envmap_free.  device < 0: the current device.  SURVEY 8f row 4. */
+typedef struct PtrEnvTables PtrEnvTables;
+int ptr_envmap_build(int device, const float *rgb, int width, int height, const float *scale3, PtrEnvTables **out);
+int ptr_envmap_view(const PtrEnvTables *tables, PtrEnvMap *view, double *build_ms);
+int ptr_envmap_free(PtrEnvTables *tables);
 /* Who builds the geometry BVHs (one per mesh / particle cloud) inside ptr_scene_build / ptr_scene_upload, process-wide:
  *   PTR_BVH_HOST_SAH     binned SAH on the host (default)
  *   PTR_BVH_DEVICE_LBVH  linear BVH on the current HIP device (Morton codes, radix sort, Karras hierarchy, refit, collapse

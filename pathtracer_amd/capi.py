@@ -110,6 +110,9 @@ HIP_SIGNATURES = {
     "ptr_last_error": (C.c_char_p, []),
     "ptr_set_stream": (C.c_int, [CTX, C.c_void_p]),
     "ptr_scene_upload": (C.c_int, [CTX, C.POINTER(PtrFlatScene)]),
+    "ptr_envmap_build": (C.c_int, [C.c_int, C.POINTER(C.c_float), C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_void_p)]),
+    "ptr_envmap_view": (C.c_int, [C.c_void_p, C.POINTER(PtrEnvMap), C.POINTER(C.c_double)]),
+    "ptr_envmap_free": (C.c_int, [C.c_void_p]),
     "ptr_scene_build_mode": (C.c_int, [C.c_int]),
     "ptr_bvh_build_info": (C.c_int, [CTX, C.POINTER(PtrBvhBuildInfo)]),
     "ptr_scene_built_info": (C.c_int, [C.c_void_p, C.POINTER(PtrBvhBuildInfo)]),
@@ -142,6 +145,8 @@ HIP_SIGNATURES = {
 }
 HOST_SIGNATURES = {
     "pth_scene_build": (C.c_void_p, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "pth_lightmap_scene": (C.c_void_p, [C.POINTER(C.c_float), C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int]),
+    "SetLightMapBuilderC": (None, [C.c_int]),
     "pth_scene_flat": (C.POINTER(PtrFlatScene), [C.c_void_p]),
     "pth_scene_camera": (None, [C.c_void_p, C.POINTER(PtrCamera)]),
     "pth_scene_rand_calls": (C.c_int, [C.c_void_p]),

@@ -59,6 +59,14 @@ struct HostScene {
     size_t sah_of_items = 0;
 };
 
+/* light-map tables of one environment map (rt_envmap.hip), host copies */
+struct HostEnvTables {
+    int width = 0, height = 0, nu = 0, nv = 0;
+    std::vector<float> texels, func, cdf, func_int, marg_cdf;
+    float marg_int = 0;
+    double build_ms = 0;
+};
+int ptr_gpu_build_envmap(const float *rgb, int width, int height, const float scale[3], HostEnvTables *out, double *ms, std::string *err);
 /* geometry BVH of one mesh / particle cloud on the current device (rt_build.hip) */
 int ptr_gpu_build_geom(const float *boxes6, const Item48 *raw, size_t n_items, std::vector<Node128> *nodes, std::vector<Item48> *items, int32_t *root,
                        float *bound6, int *depth, double *ms, std::string *err);

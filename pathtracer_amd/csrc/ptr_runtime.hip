@@ -877,6 +877,37 @@ int ptr_scene_build(const PtrFlatScene *scene, PtrBuiltScene **out) {
     *out = b;
     return PTR_OK;
 }
+struct PtrEnvTables {
+    HostEnvTables t;
+};
+int ptr_envmap_build(int device, const float *rgb, int width, int height, const float *scale3, PtrEnvTables **out) {
+    if (!out) return set_err(PTR_ERR_INVALID, "null out pointer");
+    *out = nullptr;
+    if (!rgb || !scale3 || width <= 0 || height <= 0 || (int64_t)width * height > (1 << 28)) return set_err(PTR_ERR_INVALID, "bad environment map");
+    if (device >= 0 && hipSetDevice(device) != hipSuccess) return set_err(PTR_ERR_HIP, "hipSetDevice failed");
+    PtrEnvTables *e = new PtrEnvTables();
+    std::string err;
+    int rc = ptr_gpu_build_envmap(rgb, width, height, scale3, &e->t, &e->t.build_ms, &err);
+    if (rc) {
+        delete e;
+        return set_err(rc, err);
+    }
+    *out = e;
+    return PTR_OK;
+}
+int ptr_envmap_view(const PtrEnvTables *tables, PtrEnvMap *view, double *build_ms) {
+    if (!tables || !view) return set_err(PTR_ERR_INVALID, "null argument");
+    const HostEnvTables &t = tables->t;
+    view->width = t.width; view->height = t.height; view->nu = t.nu; view->nv = t.nv;
+    view->texels = t.texels.data(); view->func = t.func.data(); view->cdf = t.cdf.data();
+    view->func_int = t.func_int.data(); view->marg_cdf = t.marg_cdf.data(); view->marg_int = t.marg_int;
+    if (build_ms) *build_ms = t.build_ms;
+    return PTR_OK;
+}
+int ptr_envmap_free(PtrEnvTables *tables) {
+    delete tables;
+    return PTR_OK;
+}
 int ptr_scene_build_mode(int mode) {
     if (mode != PTR_BVH_HOST_SAH && mode != PTR_BVH_DEVICE_LBVH) return set_err(PTR_ERR_INVALID, "unknown BVH build mode");
     ptr_bvh_build_mode_set(mode);

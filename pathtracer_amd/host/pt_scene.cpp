@@ -435,8 +435,42 @@ static void Distribution1D(const Float *f, int n, Float *cdf, Float *funcInt) { 
     if (*funcInt == 0) for (int i = 1; i < n + 1; ++i) cdf[i] = Float(i) / Float(n);
     else for (int i = 1; i < n + 1; ++i) cdf[i] /= *funcInt;
 }
+static int g_lightmap_on_device = -1;
+void SetLightMapBuilder(int on_device) { g_lightmap_on_device = on_device ? 1 : 0; }
+static bool lightmap_on_device() {
+    if (g_lightmap_on_device < 0) {
+        const char *e = getenv("PTR_ENVMAP_BUILD");
+        g_lightmap_on_device = (e && !strcmp(e, "device")) ? 1 : 0;
+    }
+    return g_lightmap_on_device == 1;
+}
 void InsertLightMap(const Spectrum *pixels, int width, int height, const Transform &toWorld, const Spectrum &scale) {
     if (g_lightMap.valid) { printf("Warning: Multiple calls to InsertLightMap\n"); return; }
+    if (lightmap_on_device()) { /* the device pipeline (csrc/rt_envmap.hip) */
+        static_assert(sizeof(Spectrum) == 3 * sizeof(float), "Spectrum is three floats");
+        const float sc3[3] = {scale.x, scale.y, scale.z};
+        PtrEnvTables *tables = nullptr;
+        if (ptr_envmap_build(-1, reinterpret_cast<const float *>(pixels), width, height, sc3, &tables) != PTR_OK) {
+            fprintf(stderr, "[pathtracer_amd] InsertLightMap: %s\n", ptr_last_error());
+            exit(1);
+        }
+        PtrEnvMap v;
+        memset(&v, 0, sizeof(v));
+        ptr_envmap_view(tables, &v, nullptr);
+        LightMapState &lm = g_lightMap;
+        lm.toWorld = toWorld;
+        lm.width = v.width; lm.height = v.height; lm.nu = v.nu; lm.nv = v.nv;
+        lm.texels.resize((size_t)v.width * v.height);
+        memcpy((void *)lm.texels.data(), v.texels, sizeof(float) * 3 * (size_t)v.width * v.height);
+        lm.func.assign(v.func, v.func + (size_t)v.nu * v.nv);
+        lm.cdf.assign(v.cdf, v.cdf + (size_t)(v.nu + 1) * v.nv);
+        lm.funcInt.assign(v.func_int, v.func_int + v.nv);
+        lm.margCdf.assign(v.marg_cdf, v.marg_cdf + v.nv + 1);
+        lm.margInt = v.marg_int;
+        lm.valid = true;
+        ptr_envmap_free(tables);
+        return;
+    }
     std::vector<Spectrum> L(pixels, pixels + (size_t)width * height);
     for (auto &p : L) p = p * scale;
     int rx = width, ry = height;

@@ -145,6 +145,9 @@ void InsertCameraMedium(MediumDescriptor medium);
 void InsertEXRLightMap(const char *path, const Transform &toWorld, const Spectrum &scale);
 /* same pipeline (BuildSpectrumMipMap + CreateDistribution2D) from pixels already in memory */
 void InsertLightMap(const Spectrum *pixels, int width, int height, const Transform &toWorld, const Spectrum &scale);
+/* where that pipeline runs: 0 = on the host (default), 1 = on the current HIP device (ptr_envmap_build: the same tables,
+ * bit for bit).  Environment PTR_ENVMAP_BUILD=device selects 1 at start-up.  No counterpart in the reference. */
+void SetLightMapBuilder(int on_device);
 
 void InsertPrimitive(SphereDescriptor shape, MaterialDescriptor mat);
 void InsertPrimitive(RectDescriptor shape, MaterialDescriptor mat);

@@ -453,6 +453,24 @@ struct BuiltScene {
 
 extern "C" {
 
+/* The light-map tables of arbitrary pixels through InsertLightMap, on the host (on_device = 0) or the device (1): what the
+ * tests compare.  Returns the flattened scene that holds them (an empty scene with a sky); pth_scene_flat / pth_scene_free. */
+void *pth_lightmap_scene(const float *rgb, int width, int height, const float *scale3, int on_device) {
+    BuiltScene *b = new BuiltScene();
+    b->rand_calls = 0;
+    Aggregator dummy;
+    dummy.ctx = (PtrContext *)1;
+    BeginScene(&dummy);
+    b->camera.Config(Point3f(0, 0, 5), Point3f(0, 0, 0), vec3f(0, 1, 0), 40, 1);
+    SetLightMapBuilder(on_device);
+    InsertLightMap(reinterpret_cast<const Spectrum *>(rgb), width, height, Translate(0, 0, 0), Spectrum(scale3[0], scale3[1], scale3[2]));
+    SetLightMapBuilder(0);
+    b->flat = FlattenScene();
+    return b;
+}
+
+void SetLightMapBuilderC(int on_device) { SetLightMapBuilder(on_device); }
+
 /* name: "cornell" | "knot" | "zoo" | "volcaustic" | "fluid" | "subsurface" | "origami" | "furnace" | "room"; p0/p1: size and variant */
 void *pth_scene_build(const char *name, int width, int height, int p0, int p1) {
     std::string n(name);
