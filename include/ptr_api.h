@@ -56,7 +56,11 @@ enum {
     PTR_MAT_UBER = 7,
     PTR_MAT_SUBSURFACE = 8,
     PTR_MAT_KDSUBSURFACE = 9,
-    PTR_MAT_PLAYGROUND = 10
+    PTR_MAT_PLAYGROUND = 10,
+    /* The reference's five Disney lobes (reflection.h:53-57,90-129; reflection.cpp:232-295, 504-521), which no material of
+     * the reference instantiates, assembled the way PBRT-v3's DisneyMaterial assembles its own.  Texture slots: 0 colour
+     * (Spectrum), 1 roughness, 2 sheen, 3 sheenTint, 4 clearcoat, 5 clearcoatGloss, 6 flatness (Floats). */
+    PTR_MAT_DISNEY = 11
 };
 
 /* Integrator selector: the reference picks one by editing src/main.cpp:444-447 */

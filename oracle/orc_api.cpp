@@ -153,7 +153,7 @@ void *orc_scene_create(const PtrFlatScene *fs, int rand_calls_before, int meshfi
             pr.emissive = true;
             pr.L = V3(pp.mat.textures[0].spec[0], pp.mat.textures[0].spec[1], pp.mat.textures[0].spec[2]);
         } else {
-            if (!pp.no_mat && pp.mat.type >= Matte && pp.mat.type <= PlayGround) {
+            if (!pp.no_mat && pp.mat.type >= Matte && pp.mat.type <= Disney) {
                 Material m;
                 m.type = pp.mat.type;
                 m.ntex = pp.mat.n_textures;

@@ -146,10 +146,38 @@ static V3 MF_Sample_wh(const MicrofacetDistribution &m, const V3 &wo, const V2 &
 static Float pow5(Float v) { return v * v * v * v * v; }
 static V3 SchlickFresnel(Float cosTheta, const V3 &Rs) { return Rs + pow5(1 - cosTheta) * (V3(1.) - Rs); }
 
+/* ---- Disney helpers, reflection.cpp:3-26 ---- */
+static Float SchlickWeight(Float cosTheta) {
+    Float m = Clampf(1 - cosTheta, 0, 1);
+    return (m * m) * (m * m) * m;
+}
+static Float FrSchlick(Float R0, Float cosTheta) { Float t = SchlickWeight(cosTheta); return (1 - t) * R0 + t * 1.f; } /* Lerp(t, R0, 1), geometry.h:1025 */
+static Float GTR1(Float cosTheta, Float alpha) {
+    if (alpha > 1) return ORC_InvPi;
+    Float alpha2 = alpha * alpha;
+    return (alpha2 - 1) / (ORC_Pi * std::log(alpha2) * (1 + (alpha2 - 1) * cosTheta * cosTheta));
+}
+static Float smithG_GGX(Float cosTheta, Float alpha) {
+    Float alpha2 = alpha * alpha;
+    Float cosTheta2 = cosTheta * cosTheta;
+    return 2.f / (1.f + std::sqrt(alpha2 + (1.0f - alpha2) * cosTheta2));
+}
+static Float DisneyClearcoat_Pdf(const BxDF &b, const V3 &wo, const V3 &wi) { /* :77-84 */
+    if (!SameHemisphere(wo, wi)) return 0;
+    V3 wh = wi + wo;
+    if (IsBlack(wh)) return 0;
+    wh = Normalize(wh);
+    Float Dr = GTR1(AbsCosTheta(wh), b.B);
+    return Dr * AbsCosTheta(wh) / (4 * Dot(wo, wh));
+}
+
 Float BxDF_Pdf(const BxDF &b, const V3 &wo, const V3 &wi) { /* :36-147 */
     if (!b.is_valid) return 0;
     switch (b.impl) {
-    case LambertianReflection: case OrenNayar: case BSSRDFAdapter: return SameHemisphere(wo, wi) ? AbsCosTheta(wi) * ORC_InvPi : 0;
+    case LambertianReflection: case OrenNayar: case BSSRDFAdapter:
+    case DisneySheen: case DisneyRetro: case DisneyFakeSS: case DisneyDiffuse: /* :128-133 */
+        return SameHemisphere(wo, wi) ? AbsCosTheta(wi) * ORC_InvPi : 0;
+    case DisneyClearcoat: return DisneyClearcoat_Pdf(b, wo, wi);
     case LambertianTransmission: return !SameHemisphere(wo, wi) ? AbsCosTheta(wi) * ORC_InvPi : 0;
     case MicrofacetTransmission: {
         if (SameHemisphere(wo, wi)) return 0;
@@ -233,6 +261,51 @@ V3 BxDF_f(const BxDF &b, const V3 &wo, const V3 &wi) { /* :149-367 */
         f *= b.bssrdf->eta * b.bssrdf->eta;
         return f;
     }
+    case DisneyDiffuse: { /* :232-239 */
+        Float Fo = SchlickWeight(AbsCosTheta(wo));
+        Float Fi = SchlickWeight(AbsCosTheta(wi));
+        return b.S * ORC_InvPi * (1 - Fo / 2) * (1 - Fi / 2);
+    }
+    case DisneyFakeSS: { /* :241-256 */
+        V3 wh = wi + wo;
+        if (IsBlack(wh)) return V3(0.);
+        wh = Normalize(wh);
+        Float cosThetaD = Dot(wi, wh);
+        Float Fss90 = cosThetaD * cosThetaD * b.A;
+        Float Fo = SchlickWeight(AbsCosTheta(wo)), Fi = SchlickWeight(AbsCosTheta(wi));
+        Float Fss = ((1 - Fo) * 1.0f + Fo * Fss90) * ((1 - Fi) * 1.0f + Fi * Fss90); /* Lerp(Fo, 1, Fss90) * Lerp(Fi, 1, Fss90) */
+        Float ss = 1.25f * (Fss * (1 / (AbsCosTheta(wo) + AbsCosTheta(wi)) - .5f) + .5f);
+        return b.S * ORC_InvPi * ss;
+    }
+    case DisneyRetro: { /* :258-270 */
+        V3 wh = wi + wo;
+        if (IsBlack(wh)) return V3(0.);
+        wh = Normalize(wh);
+        Float cosThetaD = Dot(wi, wh);
+        Float Fo = SchlickWeight(AbsCosTheta(wo));
+        Float Fi = SchlickWeight(AbsCosTheta(wi));
+        Float Rr = 2 * b.A * cosThetaD * cosThetaD;
+        return b.S * ORC_InvPi * Rr * (Fo + Fi + Fo * Fi * (Rr - 1));
+    }
+    case DisneySheen: { /* :272-285 */
+        V3 wh = wi + wo;
+        if (IsBlack(wh)) return V3(0.);
+        wh = Normalize(wh);
+        Float cosThetaD = Absf(Dot(wi, wh));
+        Float luminance = Dot(V3(0.3f, 0.6f, 1.0f), b.S);
+        V3 tint = (luminance > 0) ? b.S * (1.f / luminance) : V3(1);
+        Float fSch = SchlickWeight(cosThetaD);
+        return b.sheen * ((1 - b.sheenTint) * V3(1) + b.sheenTint * tint) * fSch;
+    }
+    case DisneyClearcoat: { /* :287-295 */
+        V3 wh = wi + wo;
+        if (IsBlack(wh)) return V3(0.);
+        wh = Normalize(wh);
+        Float Dr = GTR1(AbsCosTheta(wh), b.B);
+        Float Fr = FrSchlick(.04, Dot(wo, wh));
+        Float Gr = smithG_GGX(AbsCosTheta(wo), .25) * smithG_GGX(AbsCosTheta(wi), .25);
+        return V3(b.A * Gr * Fr * Dr / 4);
+    }
     default: return V3(0.f);
     }
 }
@@ -241,10 +314,24 @@ V3 BxDF_Sample_f(const BxDF &b, const V3 &wo, V3 *wi, const V2 &u, Float *pdf, i
     if (!b.is_valid) { *pdf = 0; return V3(0); }
     switch (b.impl) {
     case LambertianReflection: case OrenNayar: case BSSRDFAdapter:
+    case DisneySheen: case DisneyRetro: case DisneyFakeSS: case DisneyDiffuse: /* :568-574 */
         *wi = CosineSampleHemisphere(u);
         if (wo.z < 0) wi->z *= -1;
         *pdf = BxDF_Pdf(b, wo, *wi);
         return BxDF_f(b, wo, *wi);
+    case DisneyClearcoat: { /* :504-521 */
+        if (IsZero(wo.z)) return V3(0.);
+        Float alpha2 = b.B * b.B;
+        Float cosTheta = std::sqrt(Max(Float(0), (1 - std::pow(alpha2, 1 - u.x)) / (1 - alpha2)));
+        Float sinTheta = std::sqrt(Max((Float)0, 1 - cosTheta * cosTheta));
+        Float phi = 2 * ORC_Pi * u.y;
+        V3 wh(sinTheta * std::cos(phi), sinTheta * std::sin(phi), cosTheta); /* SphericalDirection, geometry.h:1470 */
+        if (!SameHemisphere(wo, wh)) wh = -wh;
+        *wi = Reflect(wo, wh);
+        if (!SameHemisphere(wo, *wi)) return V3(0.f);
+        *pdf = BxDF_Pdf(b, wo, *wi);
+        return BxDF_f(b, wo, *wi);
+    }
     case LambertianTransmission:
         *wi = CosineSampleHemisphere(u);
         if (wo.z > 0) wi->z *= -1;
@@ -591,6 +678,30 @@ void ComputeScatteringFunctions(const Scene &sc, SurfaceInteraction *si, BSDF *b
         SubsurfaceFromDiffuse(sc.tables[m.bssrdfTable], kd, mfree, &sig_a, &sig_s);
         InitTabulatedBSSRDF(&bsdf->bssrdf, *si, eta, pr.material, sig_a, sig_s, &sc.tables[m.bssrdfTable]);
         bsdf->has_bssrdf = 1;
+    } break;
+    case Disney: { /* No material of the reference pushes its Disney lobes (reflection.h:90-129 are never called); this is
+                      how PBRT-v3's DisneyMaterial assembles the same five, without the metallic / transmission / specular
+                      terms the reference has no lobes for.  Slots: 0 colour, 1 roughness, 2 sheen, 3 sheenTint, 4 clearcoat,
+                      5 clearcoatGloss, 6 flatness.  Init_DisneyClearcoat stores its arguments in clearCoat / alpha while
+                      f / Pdf / Sample_f read A / B (reflection.h:90-95 vs reflection.cpp:82,291): restated with the
+                      two numbers where they are read. */
+        V3 c = EvalSpec(sc, tx[0], si);
+        Float rough = EvalFloat(sc, tx[1], si), sheen = EvalFloat(sc, tx[2], si), stint = EvalFloat(sc, tx[3], si);
+        Float cc = EvalFloat(sc, tx[4], si), gloss = EvalFloat(sc, tx[5], si), flat = EvalFloat(sc, tx[6], si);
+        if (!IsBlack(c)) {
+            BxDF b;
+            b.type = BSDF_REFLECTION | BSDF_DIFFUSE;
+            b.impl = DisneyDiffuse; b.S = (1 - flat) * c; bsdf->Push(b);
+            if (flat > 0) { b.impl = DisneyFakeSS; b.S = flat * c; b.A = rough; bsdf->Push(b); }
+            b.impl = DisneyRetro; b.S = c; b.A = rough; bsdf->Push(b);
+            if (sheen > 0) { b.impl = DisneySheen; b.S = c; b.sheen = V3(sheen); b.sheenTint = stint; bsdf->Push(b); }
+        }
+        if (cc > 0) {
+            BxDF b;
+            b.type = BSDF_REFLECTION | BSDF_GLOSSY; b.impl = DisneyClearcoat;
+            b.A = cc; b.B = (1 - gloss) * .1f + gloss * .001f;
+            bsdf->Push(b);
+        }
     } break;
     case PlayGround: { /* playground.cpp:6-23 */
         V3 base = EvalSpec(sc, tx[0], si);

@@ -13,7 +13,7 @@ namespace orc {
 /* shape.h:8-11 */
 enum ShapeType { SPHERE, RECTANGLE, DISK, BOX, MESH, PARTICLECLOUD, SPHERE_PROCEDURAL, BOX_PROCEDURAL, COMPONENT_PROCEDURAL };
 /* material.h:250-254 */
-enum MaterialType { MatNone = 0, Matte = 1, Mirror, Glass, Metal, Translucent, Plastic, Uber, Subsurface, KdSubsurface, PlayGround };
+enum MaterialType { MatNone = 0, Matte = 1, Mirror, Glass, Metal, Translucent, Plastic, Uber, Subsurface, KdSubsurface, PlayGround, Disney };
 /* light.h:13-24 */
 enum { LF_DeltaPosition = 1, LF_DeltaDirection = 2, LF_Area = 4, LF_Infinite = 8 };
 enum LightType { DiffuseArea = 1, Distant, Infinite };
@@ -225,7 +225,8 @@ Float SDFMapToy(int id, const Bounds3 &bounds, const V3 &p, int *shapeId);
 /* ---- orc_bsdf.cpp ---- */
 enum BxDFType { BSDF_REFLECTION = 1, BSDF_TRANSMISSION = 2, BSDF_DIFFUSE = 4, BSDF_GLOSSY = 8, BSDF_SPECULAR = 16, BSDF_ALL = 31 };
 enum BxDFImpl { LambertianReflection = 0, LambertianTransmission, SpecularReflection, SpecularTransmission, FresnelSpecular,
-                OrenNayar, MicrofacetTransmission, MicrofacetReflection, FresnelBlend, BSSRDFAdapter };
+                OrenNayar, MicrofacetTransmission, MicrofacetReflection, FresnelBlend, BSSRDFAdapter,
+                DisneyDiffuse, DisneyFakeSS, DisneyRetro, DisneySheen, DisneyClearcoat }; /* reflection.h:53-57 */
 enum FresnelType { FrNoOp, FrDielectric, FrConductorT };
 struct Fresnel { int type; Float etaI, etaT; V3 setaI, setaT, sk; Fresnel() : type(FrNoOp) {} };
 struct MicrofacetDistribution { Float alphax, alphay; bool sampleVisibleArea; };
@@ -235,9 +236,11 @@ struct BxDF {
     V3 S, T;
     Fresnel fresnel;
     Float A, B;
+    V3 sheen;        /* reflection.h:76-80: Disney sheen colour and tint factor */
+    Float sheenTint;
     MicrofacetDistribution mDist;
     const SeparableBSSRDF *bssrdf;
-    BxDF() : type(0), impl(0), is_valid(1), A(0), B(0), bssrdf(nullptr) {}
+    BxDF() : type(0), impl(0), is_valid(1), A(0), B(0), sheenTint(0), bssrdf(nullptr) {}
     bool MatchesFlags(int t) const { return (type & t) == type; }
 };
 struct SeparableBSSRDF { /* bssrdf.h:84-160 (tabulated only: nothing instantiates Disney) */

@@ -11,9 +11,9 @@
 
 enum { BSDF_REFLECTION = 1, BSDF_TRANSMISSION = 2, BSDF_DIFFUSE = 4, BSDF_GLOSSY = 8, BSDF_SPECULAR = 16, BSDF_ALL = 31 };
 enum { LB_LAMBERT_R = 0, LB_LAMBERT_T, LB_SPEC_R, LB_SPEC_T, LB_FRESNEL_SPEC, LB_OREN_NAYAR, LB_MICRO_T, LB_MICRO_R, LB_FRESNEL_BLEND,
-       LB_BSSRDF_ADAPTER, LB_INVALID };
+       LB_BSSRDF_ADAPTER, LB_DISNEY_DIFFUSE, LB_DISNEY_FAKESS, LB_DISNEY_RETRO, LB_DISNEY_SHEEN, LB_DISNEY_CLEARCOAT, LB_INVALID };
 enum { FR_NOOP = 0, FR_DIELECTRIC = 1, FR_CONDUCTOR = 2 };
-enum { MT_MATTE = 1, MT_MIRROR, MT_GLASS, MT_METAL, MT_TRANSLUCENT, MT_PLASTIC, MT_UBER, MT_SUBSURFACE, MT_KDSUBSURFACE, MT_PLAYGROUND };
+enum { MT_MATTE = 1, MT_MIRROR, MT_GLASS, MT_METAL, MT_TRANSLUCENT, MT_PLASTIC, MT_UBER, MT_SUBSURFACE, MT_KDSUBSURFACE, MT_PLAYGROUND, MT_DISNEY };
 #ifndef MAX_LOBES
 #define MAX_LOBES 5
 #endif
@@ -25,8 +25,8 @@ struct Lobe { /* 16 words; a field is written only by the lobe kinds that read i
     int type, impl;
     f3 S;         /* reflectance (BxDF::S) */
     f3 T;         /* transmittance (BxDF::T); conductor lobes: etaT spectrum (etaI is always 1) */
-    float A, B;   /* eta pair, or Oren-Nayar A,B; conductor lobes: k.x, k.y */
-    float C;      /* conductor lobes: k.z; BSSRDF adapter: eta of the owning BSSRDF */
+    float A, B;   /* eta pair, or Oren-Nayar A,B; conductor lobes: k.x, k.y; Disney: roughness (fake-SS, retro), clearcoat weight / gloss alpha */
+    float C;      /* conductor lobes: k.z; BSSRDF adapter: eta of the owning BSSRDF; Disney sheen: sheenTint (T = sheen) */
     float ax, ay; /* Trowbridge-Reitz alphas */
     int fr_type;
     float fr_etaI, fr_etaT;
@@ -190,10 +190,36 @@ PD f3 bssrdf_sw(float eta, const f3 &w) {
     return f3((float)((1 - fr_dielectric(cos_theta(w), 1, eta)) / (c * kPi)));
 }
 
+/* ---- Disney lobes, reflection.cpp:3-26, 77-84, 232-295, 504-521 ---- */
+PD float schlick_weight(float cosTheta) {
+    float m = clampr(1 - cosTheta, 0, 1);
+    return (m * m) * (m * m) * m;
+}
+PD float gtr1(float cosTheta, float alpha) { /* Pi is a double literal in the reference: the quotient is taken in double */
+    if (alpha > 1) return (float)kInvPi;
+    float alpha2 = alpha * alpha;
+    return (float)((alpha2 - 1) / (kPi * logf(alpha2) * (1 + (alpha2 - 1) * cosTheta * cosTheta)));
+}
+PD float smith_g_ggx(float cosTheta, float alpha) {
+    float alpha2 = alpha * alpha;
+    float cosTheta2 = cosTheta * cosTheta;
+    return 2.f / (1.f + sqrtf(alpha2 + (1.0f - alpha2) * cosTheta2));
+}
+PD float disney_clearcoat_pdf(const Lobe &b, const f3 &wo, const f3 &wi) {
+    if (!same_hemisphere(wo, wi)) return 0;
+    f3 wh = wi + wo;
+    if (is_black(wh)) return 0;
+    wh = normalize(wh);
+    float Dr = gtr1(abs_cos_theta(wh), b.B);
+    return Dr * abs_cos_theta(wh) / (4 * dot(wo, wh));
+}
+
 LOBE_FN float lobe_pdf_v(Lobe b, float wox, float woy, float woz, float wix, float wiy, float wiz) {
     const f3 wo(wox, woy, woz), wi(wix, wiy, wiz);
     switch (b.impl) {
-    case LB_LAMBERT_R: case LB_OREN_NAYAR: case LB_BSSRDF_ADAPTER: return same_hemisphere(wo, wi) ? abs_cos_theta(wi) * kInvPi : 0;
+    case LB_LAMBERT_R: case LB_OREN_NAYAR: case LB_BSSRDF_ADAPTER:
+    case LB_DISNEY_DIFFUSE: case LB_DISNEY_FAKESS: case LB_DISNEY_RETRO: case LB_DISNEY_SHEEN: return same_hemisphere(wo, wi) ? abs_cos_theta(wi) * kInvPi : 0;
+    case LB_DISNEY_CLEARCOAT: return disney_clearcoat_pdf(b, wo, wi);
     case LB_LAMBERT_T: return !same_hemisphere(wo, wi) ? abs_cos_theta(wi) * kInvPi : 0;
     case LB_MICRO_T: {
         if (same_hemisphere(wo, wi)) return 0;
@@ -276,6 +302,50 @@ LOBE_FN f3 lobe_f_v(Lobe b, float wox, float woy, float woz, float wix, float wi
         f *= b.C * b.C;
         return f;
     }
+    case LB_DISNEY_DIFFUSE: {
+        float Fo = schlick_weight(abs_cos_theta(wo)), Fi = schlick_weight(abs_cos_theta(wi));
+        return b.S * (float)kInvPi * (1 - Fo / 2) * (1 - Fi / 2);
+    }
+    case LB_DISNEY_FAKESS: {
+        f3 wh = wi + wo;
+        if (is_black(wh)) return f3(0.f);
+        wh = normalize(wh);
+        float cosThetaD = dot(wi, wh);
+        float Fss90 = cosThetaD * cosThetaD * b.A;
+        float Fo = schlick_weight(abs_cos_theta(wo)), Fi = schlick_weight(abs_cos_theta(wi));
+        float Fss = ((1 - Fo) * 1.0f + Fo * Fss90) * ((1 - Fi) * 1.0f + Fi * Fss90);
+        float ss = 1.25f * (Fss * (1 / (abs_cos_theta(wo) + abs_cos_theta(wi)) - .5f) + .5f);
+        return b.S * (float)kInvPi * ss;
+    }
+    case LB_DISNEY_RETRO: {
+        f3 wh = wi + wo;
+        if (is_black(wh)) return f3(0.f);
+        wh = normalize(wh);
+        float cosThetaD = dot(wi, wh);
+        float Fo = schlick_weight(abs_cos_theta(wo)), Fi = schlick_weight(abs_cos_theta(wi));
+        float Rr = 2 * b.A * cosThetaD * cosThetaD;
+        return b.S * (float)kInvPi * Rr * (Fo + Fi + Fo * Fi * (Rr - 1));
+    }
+    case LB_DISNEY_SHEEN: {
+        f3 wh = wi + wo;
+        if (is_black(wh)) return f3(0.f);
+        wh = normalize(wh);
+        float cosThetaD = absr(dot(wi, wh));
+        float luminance = 0.3f * b.S.x + 0.6f * b.S.y + 1.0f * b.S.z; /* CalculateTint, reflection.cpp:272-275 */
+        f3 tint = (luminance > 0) ? b.S * (1.f / luminance) : f3(1.f);
+        float fSch = schlick_weight(cosThetaD);
+        return b.T * ((1 - b.C) * f3(1.f) + b.C * tint) * fSch;
+    }
+    case LB_DISNEY_CLEARCOAT: {
+        f3 wh = wi + wo;
+        if (is_black(wh)) return f3(0.f);
+        wh = normalize(wh);
+        float Dr = gtr1(abs_cos_theta(wh), b.B);
+        float w = schlick_weight(dot(wo, wh));
+        float Fr = (1 - w) * .04f + w * 1.f;
+        float Gr = smith_g_ggx(abs_cos_theta(wo), .25f) * smith_g_ggx(abs_cos_theta(wi), .25f);
+        return f3(b.A * Gr * Fr * Dr / 4);
+    }
     default: return f3(0.f);
     }
 }
@@ -297,10 +367,24 @@ PD f3 lobe_sample_f(const Lobe &b, const f3 &wo, f3 *wi, const f2 &u, float *pdf
 PD f3 lobe_sample_f_body(const Lobe &b, const f3 &wo, f3 *wi, const f2 &u, float *pdf, int *sampledType) {
     switch (b.impl) {
     case LB_LAMBERT_R: case LB_OREN_NAYAR: case LB_BSSRDF_ADAPTER:
+    case LB_DISNEY_DIFFUSE: case LB_DISNEY_FAKESS: case LB_DISNEY_RETRO: case LB_DISNEY_SHEEN:
         *wi = cosine_sample_hemisphere(u);
         if (wo.z < 0) wi->z *= -1;
         *pdf = lobe_pdf(b, wo, *wi);
         return lobe_f(b, wo, *wi);
+    case LB_DISNEY_CLEARCOAT: {
+        if (is_zero(wo.z)) return f3(0.f);
+        float alpha2 = b.B * b.B;
+        float cosTheta = sqrtf(fmaxr(0.f, (1 - powf(alpha2, 1 - u.x)) / (1 - alpha2)));
+        float sinTheta = sqrtf(fmaxr(0.f, 1 - cosTheta * cosTheta));
+        float phi = 2 * kPi * u.y;
+        f3 wh(sinTheta * cosf(phi), sinTheta * sinf(phi), cosTheta);
+        if (!same_hemisphere(wo, wh)) wh = -wh;
+        *wi = reflect(wo, wh);
+        if (!same_hemisphere(wo, *wi)) return f3(0.f);
+        *pdf = lobe_pdf(b, wo, *wi);
+        return lobe_f(b, wo, *wi);
+    }
     case LB_LAMBERT_T:
         *wi = cosine_sample_hemisphere(u);
         if (wo.z > 0) wi->z *= -1;
@@ -639,6 +723,23 @@ PD bool compute_scattering(const DScene &sc, const SI &si, BSDF *bsdf, BssrdfPar
         bp->has = 1; bp->eta = eta; bp->table = m.table; bp->kd_mode = 1;
         bp->kd = tex_spec(sc, tx[0], uv);
         bp->mfree = scale * tex_spec(sc, tx[3], uv);
+    } break;
+    case MT_DISNEY: { /* the reference's five Disney lobes assembled as PBRT-v3's DisneyMaterial assembles its own (no metallic /
+                         transmission / specular terms: the reference has no lobes for them).  Slots: 0 colour, 1 roughness,
+                         2 sheen, 3 sheenTint, 4 clearcoat, 5 clearcoatGloss, 6 flatness */
+        f3 c = tex_spec(sc, tx[0], uv);
+        float rough = tex_float(sc, tx[1], uv), sheen = tex_float(sc, tx[2], uv), stint = tex_float(sc, tx[3], uv);
+        float cc = tex_float(sc, tx[4], uv), gloss = tex_float(sc, tx[5], uv), flat = tex_float(sc, tx[6], uv);
+        Lobe l;
+        if (!is_black(c)) {
+            lobe_clear(l); l.type = BSDF_REFLECTION | BSDF_DIFFUSE; l.impl = LB_DISNEY_DIFFUSE; l.S = (1 - flat) * c; lobe_push(bsdf, l);
+            if (flat > 0) { lobe_clear(l); l.type = BSDF_REFLECTION | BSDF_DIFFUSE; l.impl = LB_DISNEY_FAKESS; l.S = flat * c; l.A = rough; lobe_push(bsdf, l); }
+            lobe_clear(l); l.type = BSDF_REFLECTION | BSDF_DIFFUSE; l.impl = LB_DISNEY_RETRO; l.S = c; l.A = rough; lobe_push(bsdf, l);
+            if (sheen > 0) { lobe_clear(l); l.type = BSDF_REFLECTION | BSDF_DIFFUSE; l.impl = LB_DISNEY_SHEEN; l.S = c; l.T = f3(sheen); l.C = stint; lobe_push(bsdf, l); }
+        }
+        if (cc > 0) { /* Init_DisneyClearcoat (reflection.h:90-95) with its two numbers in the fields the lobe reads (A, B) */
+            lobe_clear(l); l.type = BSDF_REFLECTION | BSDF_GLOSSY; l.impl = LB_DISNEY_CLEARCOAT; l.A = cc; l.B = (1 - gloss) * .1f + gloss * .001f; lobe_push(bsdf, l);
+        }
     } break;
     case MT_PLAYGROUND: {
         f3 base = tex_spec(sc, tx[0], uv);

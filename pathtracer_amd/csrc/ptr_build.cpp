@@ -685,7 +685,7 @@ int ptr_flatten(const PtrFlatScene *fs, HostScene *hs, std::string *err) {
             pr.flags |= PF_EMISSIVE;
             for (int k = 0; k < 3; k++) pr.L[k] = pp.mat.textures[0].spec[k];
         } else {
-            if (!pp.no_mat && pp.mat.type >= PTR_MAT_MATTE && pp.mat.type <= PTR_MAT_PLAYGROUND) {
+            if (!pp.no_mat && pp.mat.type >= PTR_MAT_MATTE && pp.mat.type <= PTR_MAT_DISNEY) {
                 DMat m;
                 memset(&m, 0, sizeof(m));
                 m.type = pp.mat.type;

@@ -316,6 +316,13 @@ MaterialDescriptor MakePlasticMaterial(Spectrum kd, Spectrum ks, Float rough) {
     MaterialDescriptor d = blank(Plastic);
     d.textures[0] = MakeTexture(kd); d.textures[1] = MakeTexture(ks); d.textures[2] = MakeTexture(rough); d.specs_taken = 3; return d;
 }
+MaterialDescriptor MakeDisneyMaterial(Spectrum color, Float roughness, Float sheen, Float sheenTint, Float clearcoat, Float clearcoatGloss,
+                                      Float flatness) {
+    MaterialDescriptor d = blank(Disney);
+    d.textures[0] = MakeTexture(color); d.textures[1] = MakeTexture(roughness); d.textures[2] = MakeTexture(sheen);
+    d.textures[3] = MakeTexture(sheenTint); d.textures[4] = MakeTexture(clearcoat); d.textures[5] = MakeTexture(clearcoatGloss);
+    d.textures[6] = MakeTexture(flatness); d.specs_taken = 7; return d;
+}
 MaterialDescriptor MakeUberMaterial(Spectrum kd, Spectrum ks, Spectrum kr, Spectrum kt, Float uRough, Float vRough, Spectrum op,
                                     Float eta) {
     MaterialDescriptor d = blank(Uber);

@@ -14,7 +14,7 @@
 enum ShapeType { /* shape.h:8-11 */
     SPHERE, RECTANGLE, DISK, BOX, MESH, PARTICLECLOUD, SPHERE_PROCEDURAL, BOX_PROCEDURAL, COMPONENT_PROCEDURAL,
 };
-enum MaterialType { Matte = 1, Mirror, Glass, Metal, Translucent, Plastic, Uber, Subsurface, KdSubsurface, PlayGround };
+enum MaterialType { Matte = 1, Mirror, Glass, Metal, Translucent, Plastic, Uber, Subsurface, KdSubsurface, PlayGround, Disney };
 enum ToneMapAlgorithm { Reinhard, Exponential, NaughtyDog }; /* camera.h:6-10 */
 
 struct ImageData { /* texture.h:10-16 */
@@ -132,6 +132,11 @@ MaterialDescriptor MakeSubsurfaceMaterial(const char *name, Float scale, Float e
 MaterialDescriptor MakeKdSubsurfaceMaterial(Spectrum kd, Spectrum kt, Spectrum kr, Spectrum mfp, Float urough, Float vrough,
                                             Float eta, Float scale);
 MaterialDescriptor MakePlasticMaterial(Spectrum kd, Spectrum ks, Float rough);
+/* The reference's Disney lobes (reflection.h:53-57) behind a material: diffuse (+ fake subsurface when flatness > 0), retro
+ * -reflection, sheen and clearcoat, assembled as PBRT-v3's DisneyMaterial does.  The reference's scene API has no such call:
+ * its lobes are never pushed. */
+MaterialDescriptor MakeDisneyMaterial(Spectrum color, Float roughness, Float sheen = 0, Float sheenTint = .5, Float clearcoat = 0,
+                                      Float clearcoatGloss = 1, Float flatness = 0);
 MaterialDescriptor MakeUberMaterial(Spectrum kd, Spectrum ks, Spectrum kr, Spectrum kt, Float uRough, Float vRough, Spectrum op,
                                     Float eta);
 MaterialDescriptor MakeTranslucentMaterial(Spectrum kd, Spectrum ks, Spectrum reflect, Spectrum transmit, Float rough);

@@ -114,8 +114,11 @@ void CornellScene(Camera *camera, Float aspect, int variant) {
     InsertPrimitive(MakeRectangle(Translate(0, 0, -(height + bottomExt) / 2) * RotateX(90), width, height + bottomExt), white);
     InsertPrimitive(MakeRectangle(Translate(0, height / 2, -28), width, height), white);
     InsertPrimitive(MakeRectangle(Translate(0, height, -height / 2) * RotateX(90), width, height), white);
-    InsertPrimitive(MakeBox(Translate(-3.5, 2, -width * 0.5) * RotateY(-25), 4, 4, 4), (variant & 1) ? glass : white);
-    InsertPrimitive(MakeBox(Translate(3.0, 4.25, -width * 0.25) * RotateY(30), 4.5, 8.5, 4.5), (variant & 1) ? mirror : white);
+    /* variant & 4: the boxes in the Disney material (all five lobes on the first, diffuse + retro + clearcoat on the second) */
+    MaterialDescriptor disney1 = MakeDisneyMaterial(Spectrum(.7, .35, .2), .6, 1.f, .5, 1.f, .8, .4);
+    MaterialDescriptor disney2 = MakeDisneyMaterial(Spectrum(.3, .45, .7), .3, 0.f, .5, .6, .2, 0.f);
+    InsertPrimitive(MakeBox(Translate(-3.5, 2, -width * 0.5) * RotateY(-25), 4, 4, 4), (variant & 4) ? disney1 : (variant & 1) ? glass : white);
+    InsertPrimitive(MakeBox(Translate(3.0, 4.25, -width * 0.25) * RotateY(30), 4.5, 8.5, 4.5), (variant & 4) ? disney2 : (variant & 1) ? mirror : white);
     MaterialDescriptor matEm = MakeEmissive(Spectrum(0.992, 0.964, 0.390) * 6);
     InsertPrimitive(MakeDisk(Translate(0, height - 0.01, -height / 2) * RotateX(90), 0, width * 0.15, 0.f, 360), matEm);
     if (variant & 2) InsertCameraMedium(MakeMedium(Spectrum(.008), Spectrum(.01), 0)); /* CornellRoomSkull, main.cpp:851 */
@@ -165,6 +168,8 @@ void FurnaceScene(Camera *camera, Float aspect, int variant) {
     MaterialDescriptor mat = variant == 1 ? MakeMirrorMaterial(Spectrum(.9))
                            : variant == 2 ? MakeGlassMaterial(Spectrum(1), Spectrum(1), 1.5)
                            : variant == 3 ? MakeGlassMaterial(Spectrum(1), Spectrum(1), 1.5, .1, .1)
+                           : variant == 8 ? MakeDisneyMaterial(Spectrum(.5, .5, .5), .5)                       /* diffuse + retro */
+                           : variant == 9 ? MakeDisneyMaterial(Spectrum(.5, .5, .5), .5, 1.f, .5, 1.f, .8, .4)  /* all five lobes */
                                           : MakeMatteMaterial(Spectrum(.5, .5, .5));
     if (variant == 4) InsertPrimitive(MakeBox(RotateY(30) * RotateX(20), 1.4, 1.4, 1.4), mat);
     else if (variant == 5) InsertPrimitive(MakeSphere(Translate(0, 0, 0), 1), MakeMedium(Spectrum(0.f), Spectrum(.8f), 0.3f));

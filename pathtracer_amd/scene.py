@@ -140,6 +140,16 @@ def material(kind, **kw):
         _tex_spec(tx[6], kw.get("opacity", (1, 1, 1)))
         _tex_float(tx[7], kw.get("eta", 1.5))
         m.n_textures = 8
+    elif kind == "disney":  # PTR_MAT_DISNEY: the reference's five Disney lobes (include/ptr_api.h)
+        m.type = capi.MAT_DISNEY
+        _tex_spec(tx[0], kw.get("color", (0.5, 0.5, 0.5)))
+        _tex_float(tx[1], kw.get("roughness", 0.5))
+        _tex_float(tx[2], kw.get("sheen", 0.0))
+        _tex_float(tx[3], kw.get("sheen_tint", 0.5))
+        _tex_float(tx[4], kw.get("clearcoat", 0.0))
+        _tex_float(tx[5], kw.get("clearcoat_gloss", 1.0))
+        _tex_float(tx[6], kw.get("flatness", 0.0))
+        m.n_textures = 7
     elif kind == "translucent":
         m.type = capi.MAT_TRANSLUCENT
         _tex_spec(tx[0], kw.get("kd", (0.25, 0.25, 0.25)))

@@ -20,6 +20,7 @@ SCENES = {
     "origami": ("origami", 0, 0),
     "subsurface": ("subsurface", 0, 0),
     "subsurface_knot": ("subsurface", 8, 0),
+    "cornell_disney": ("cornell", 0, 4),  # the boxes in the Disney material (PTR_MAT_DISNEY: the reference's five Disney lobes)
     "room": ("room", 6, 0),  # configs[2]: 40 rectangle / SDF-box primitives, 8 meshes, 64 emitters, image-textured walls
 }
 INTEGRATORS = {"direct": pa.LI_DIRECT, "path": pa.LI_PATH, "pathsampled": pa.LI_PATHSAMPLED, "volpath": pa.LI_VOLPATH}

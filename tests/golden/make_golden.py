@@ -15,7 +15,7 @@ import common  # noqa: E402
 
 W, H, SEED = 32, 24, 1234
 FMAX = np.finfo(np.float32).max
-for name in (sys.argv[1:] or ["cornell", "knot_glass", "zoo_sky_fog", "fluid", "volcaustic", "room"]):
+for name in (sys.argv[1:] or ["cornell", "knot_glass", "zoo_sky_fog", "fluid", "volcaustic", "room", "cornell_disney"]):
     sc = common.build(name, W, H)
     o = common.oracle_of(sc)
     oo, od, ow = o.generate_rays(sc.camera, W, H, SEED, 0)

@@ -17,7 +17,11 @@ ZOO_KD = {"matte": (.7, .3, .2)}
 # a scene of one sphere per material for the integral checks (material_scene below): primitive index -> material.  Translucent is
 # split into its diffuse pair (Lambertian reflection + transmission) and its glossy pair (microfacet reflection + transmission).
 MATS = {"matte": 0, "oren_nayar": 1, "mirror": 2, "glass": 3, "rough_glass": 4, "metal": 5, "plastic": 6, "translucent_diffuse": 7,
-        "translucent_glossy": 8}
+        "translucent_glossy": 8, "disney_diffuse": 9, "disney_full": 10, "disney_coat": 11}
+# the Disney material (PTR_MAT_DISNEY): diffuse + retro only; all five lobes; clearcoat alone (black base colour)
+DISNEY = {"disney_diffuse": dict(color=(.6, .5, .4), roughness=.7),
+          "disney_full": dict(color=(.6, .5, .4), roughness=.7, sheen=1.0, sheen_tint=.4, clearcoat=.8, clearcoat_gloss=.3, flatness=.35),
+          "disney_coat": dict(color=(0, 0, 0), roughness=.5, clearcoat=1.0, clearcoat_gloss=.3)}
 UNREACHABLE_T = ("rough_glass", "translucent_glossy")  # carry a MicrofacetTransmission lobe (eta 1.5)
 
 
@@ -34,6 +38,8 @@ def material_scene():
     b.sphere(1, S.material("plastic", kd=(.2, .2, .7), ks=(.6, .6, .6), roughness=.1))
     b.sphere(1, S.material("translucent", kd=(.5, .4, .3), ks=(0, 0, 0), reflect=(.6, .6, .6), transmit=(.4, .4, .4), roughness=.2))
     b.sphere(1, S.material("translucent", kd=(0, 0, 0), ks=(.3, .3, .3), reflect=(.6, .6, .6), transmit=(.4, .4, .4), roughness=.2))
+    for name in ("disney_diffuse", "disney_full", "disney_coat"):
+        b.sphere(1, S.material("disney", **DISNEY[name]))
     return b.finish()
 
 
@@ -190,13 +196,15 @@ def check_material_integrals(B, name, prim, fine=False):
             reach = ~below | (((wh @ wo.astype(np.float64)) > 0) & ((wh * wi).sum(1) < 0))
         total = (pdf * w)[reach].sum()
         # a visible-normal microfacet lobe loses the half vectors whose reflection dips below the surface: <= 1, and not by much
-        assert 0.80 < total < 1.004, (name, wo, total)
+        # (the Disney clearcoat samples GTR1 half vectors from the whole distribution, not the visible ones, and GTR1 has long
+        # tails: at grazing wo a quarter of the reflections dip below the surface)
+        assert (0.6 if name == "disney_coat" else 0.80) < total < 1.004, (name, wo, total)
         if name in ("matte", "oren_nayar"):
             assert abs(total - 1) < 2e-3
         albedo = (f * np.abs(wi[:, 2:3]) * w[:, None]).sum(0)
         # energy conservation of a lobe; plastic and translucent ADD a diffuse and a glossy lobe with no coupling (plastic.cpp,
         # translucent.cpp), so their sum may pass one by the glossy lobe's share at grazing angles - bounded by Kd + Ks
-        assert (albedo < (1.01 if name in ("matte", "oren_nayar", "metal", "rough_glass") else 1.31)).all(), (name, wo, albedo)
+        assert (albedo < (1.01 if name in ("matte", "oren_nayar", "metal", "rough_glass", "disney_diffuse", "disney_coat") else 1.31)).all(), (name, wo, albedo)
         if name == "matte":
             assert np.allclose(albedo, ZOO_KD["matte"], atol=2e-3)  # Lambert: f = R / pi
             assert np.allclose(f[wi[:, 2] > 0], np.array(ZOO_KD["matte"]) / np.pi, rtol=1e-5)
@@ -216,6 +224,61 @@ def check_material_integrals(B, name, prim, fine=False):
         f2, p2 = B.bsdf_eval(prim, np.tile(wo, (idx.size, 1)), swi[idx])
         assert np.allclose(f2, sf[idx], rtol=2e-3, atol=1e-5), name
         assert np.allclose(p2, spdf[idx], rtol=2e-3, atol=1e-5), name
+
+
+def disney_f(p, wo, wi):
+    """The five lobes from the published formulas (Burley 2012 "Physically based shading at Disney", eqs. of section 5, and
+    Burley 2015 "Extending the Disney BRDF to a BSDF with integrated subsurface scattering", eq. 4), in float64 numpy,
+    written from the papers - not from the reference, the oracle or the device code."""
+    wo, wi = wo.astype(np.float64), wi.astype(np.float64)
+    c = np.array(p.get("color", (.5, .5, .5)), np.float64)
+    rough, sheen, tint_w = p.get("roughness", .5), p.get("sheen", 0.), p.get("sheen_tint", .5)
+    cc, gloss, flat = p.get("clearcoat", 0.), p.get("clearcoat_gloss", 1.), p.get("flatness", 0.)
+    co, ci = np.abs(wo[:, 2]), np.abs(wi[:, 2])
+    h = wo + wi
+    h /= np.linalg.norm(h, axis=1, keepdims=True)
+    cd = (wi * h).sum(1)  # cos of the difference angle
+    sw = lambda x: np.clip(1 - x, 0, 1) ** 5
+    Fo, Fi = sw(co), sw(ci)
+    f = np.zeros((wo.shape[0], 3))
+    if c.any():
+        diffuse = (1 - Fo / 2) * (1 - Fi / 2) / np.pi
+        f += (1 - flat) * c * diffuse[:, None]
+        if flat > 0:  # Hanrahan-Krueger-like fake subsurface term
+            Fss90 = cd * cd * rough
+            Fss = (1 + (Fss90 - 1) * Fo) * (1 + (Fss90 - 1) * Fi)
+            f += flat * c * (1.25 * (Fss * (1 / (co + ci) - .5) + .5) / np.pi)[:, None]
+        Rr = 2 * rough * cd * cd
+        f += c * (Rr * (Fo + Fi + Fo * Fi * (Rr - 1)) / np.pi)[:, None]
+        if sheen > 0:
+            lum = .3 * c[0] + .6 * c[1] + 1. * c[2]
+            tint = c / lum if lum > 0 else np.ones(3)
+            f += sheen * ((1 - tint_w) + tint_w * tint) * sw(np.abs(cd))[:, None]
+    if cc > 0:
+        a = (1 - gloss) * .1 + gloss * .001
+        a2 = a * a
+        ch = np.abs(h[:, 2])
+        D = (a2 - 1) / (np.pi * np.log(a2) * (1 + (a2 - 1) * ch * ch))  # GTR1
+        F = .04 + .96 * sw((wo * h).sum(1))
+        g = lambda x: 2 / (1 + np.sqrt(.0625 + (1 - .0625) * x * x))  # the separable GGX masking term of the Disney clearcoat, alpha = 0.25
+        f += (cc * g(co) * g(ci) * F * D / 4)[:, None]
+    return f
+
+
+def check_disney_closed_form(B, name, prim):
+    rng = np.random.default_rng(9)
+    a, b = rng.normal(size=(6000, 3)), rng.normal(size=(6000, 3))
+    a[:, 2], b[:, 2] = np.abs(a[:, 2]) + 0.02, np.abs(b[:, 2]) + 0.02
+    a = (a / np.linalg.norm(a, axis=1, keepdims=True)).astype(np.float32)
+    b = (b / np.linalg.norm(b, axis=1, keepdims=True)).astype(np.float32)
+    f, pdf = B.bsdf_eval(prim, a, b)
+    want = disney_f(DISNEY[name], a, b)
+    assert np.allclose(f, want, rtol=2e-4, atol=2e-6), (name, np.abs(f - want).max())
+    # opposite sides of the surface: every lobe is a reflection lobe
+    b2 = b.copy()
+    b2[:, 2] *= -1
+    f2, pdf2 = B.bsdf_eval(prim, a, b2)
+    assert (f2 == 0).all() and (pdf2 == 0).all()
 
 
 def check_reciprocity(B, name, prim):

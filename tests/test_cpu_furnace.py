@@ -21,6 +21,9 @@ CASES = {
     "matte_mesh": (6, 0.5, ("direct", "path", "pathsampled", "volpath"), 0.01),
     # a ball of medium that only scatters (sigma_a = 0, g = 0.3): every photon that goes in comes out
     "scattering_ball": (5, 1.0, ("volpath",), 0.02),
+    # Disney diffuse + retro-reflection at roughness 0.5 is built to keep the Lambertian albedo (Burley 2012, section 5.3):
+    # the mean over the sphere is the base colour's 0.5 to within 2 % (tests/pins.py holds the lobes to the published formulas)
+    "disney_sphere": (8, 0.5, ("direct", "path", "pathsampled", "volpath"), 0.025),
     # a floor under a sky that is 1 above the horizon and 0 below: irradiance pi, through the Distribution2D sampling
     "floor_half_sky": (7, 0.5, ("direct", "path", "pathsampled", "volpath"), 0.01),
 }

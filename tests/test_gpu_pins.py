@@ -65,12 +65,18 @@ def test_light_map_distribution(zoo):
     pins.check_env(zoo, e.nu, e.nv)
 
 
-@pytest.mark.parametrize("name", ["matte", "oren_nayar", "plastic", "metal", "rough_glass", "translucent_diffuse", "translucent_glossy"])
+@pytest.mark.parametrize("name", ["matte", "oren_nayar", "plastic", "metal", "rough_glass", "translucent_diffuse", "translucent_glossy",
+                                  "disney_diffuse", "disney_full", "disney_coat"])
 def test_material_integrals(mats, name):
-    pins.check_material_integrals(mats, name, pins.MATS[name], fine=name in ("metal",))
+    pins.check_material_integrals(mats, name, pins.MATS[name], fine=name in ("metal", "disney_full", "disney_coat"))
 
 
-@pytest.mark.parametrize("name", ["matte", "oren_nayar", "plastic", "metal"])
+@pytest.mark.parametrize("name", ["disney_diffuse", "disney_full", "disney_coat"])
+def test_disney_lobes_against_the_published_formulas(mats, name):
+    pins.check_disney_closed_form(mats, name, pins.MATS[name])
+
+
+@pytest.mark.parametrize("name", ["matte", "oren_nayar", "plastic", "metal", "disney_diffuse", "disney_full", "disney_coat"])
 def test_reciprocity(mats, name):
     pins.check_reciprocity(mats, name, pins.MATS[name])
 
