@@ -214,8 +214,7 @@ PD float disney_clearcoat_pdf(const Lobe &b, const f3 &wo, const f3 &wi) {
     return Dr * abs_cos_theta(wh) / (4 * dot(wo, wh));
 }
 
-LOBE_FN float lobe_pdf_v(Lobe b, float wox, float woy, float woz, float wix, float wiy, float wiz) {
-    const f3 wo(wox, woy, woz), wi(wix, wiy, wiz);
+PD float lobe_pdf_body(const Lobe &b, const f3 &wo, const f3 &wi) {
     switch (b.impl) {
     case LB_LAMBERT_R: case LB_OREN_NAYAR: case LB_BSSRDF_ADAPTER:
     case LB_DISNEY_DIFFUSE: case LB_DISNEY_FAKESS: case LB_DISNEY_RETRO: case LB_DISNEY_SHEEN: return same_hemisphere(wo, wi) ? abs_cos_theta(wi) * kInvPi : 0;
@@ -245,9 +244,11 @@ LOBE_FN float lobe_pdf_v(Lobe b, float wox, float woy, float woz, float wix, flo
     default: return 0;
     }
 }
+LOBE_FN float lobe_pdf_v(Lobe b, float wox, float woy, float woz, float wix, float wiy, float wiz) {
+    return lobe_pdf_body(b, f3(wox, woy, woz), f3(wix, wiy, wiz));
+}
 PD float lobe_pdf(const Lobe &b, const f3 &wo, const f3 &wi) { return lobe_pdf_v(b, wo.x, wo.y, wo.z, wi.x, wi.y, wi.z); }
-LOBE_FN f3 lobe_f_v(Lobe b, float wox, float woy, float woz, float wix, float wiy, float wiz) {
-    const f3 wo(wox, woy, woz), wi(wix, wiy, wiz);
+PD f3 lobe_f_body(const Lobe &b, const f3 &wo, const f3 &wi) {
     switch (b.impl) {
     case LB_LAMBERT_R: case LB_LAMBERT_T: return b.S * (float)kInvPi;
     case LB_OREN_NAYAR: {
@@ -349,7 +350,15 @@ LOBE_FN f3 lobe_f_v(Lobe b, float wox, float woy, float woz, float wix, float wi
     default: return f3(0.f);
     }
 }
+LOBE_FN f3 lobe_f_v(Lobe b, float wox, float woy, float woz, float wix, float wiy, float wiz) {
+    return lobe_f_body(b, f3(wox, woy, woz), f3(wix, wiy, wiz));
+}
 PD f3 lobe_f(const Lobe &b, const f3 &wo, const f3 &wi) { return lobe_f_v(b, wo.x, wo.y, wo.z, wi.x, wi.y, wi.z); }
+/* f and pdf of one lobe for the same pair of directions.  (One out-of-line function computing both, so that the half vector
+ * and D are shared, was measured: its larger register footprint pushed the shade kernel from 4 to 27 spilled VGPRs and
+ * made it 5 % slower, so the two switches stay separate calls.) */
+struct LobeFP { f3 f; float pdf; };
+PD LobeFP lobe_f_pdf(const Lobe &b, const f3 &wo, const f3 &wi) { LobeFP r; r.f = lobe_f(b, wo, wi); r.pdf = lobe_pdf(b, wo, wi); return r; }
 /* by value in and out: everything travels in registers (a pointer argument would pin the caller's variable to scratch) */
 struct LobeSample { f3 f, wi; float pdf; int type; };
 PD f3 lobe_sample_f_body(const Lobe &b, const f3 &wo, f3 *wi, const f2 &u, float *pdf, int *sampledType);
@@ -498,6 +507,29 @@ PD float bsdf_pdf(const BSDF &b, const f3 &woW, const f3 &wiW, int flags) {
         if (type_matches(lobe_type(b, i), flags)) { pdf += lobe_pdf(lobe_load(b, i), wo, wi); matching += 1; }
     return matching > 0 ? pdf / matching : 0.f;
 }
+/* BSDF::f and BSDF::Pdf for the same directions and flags (EstimateDirect asks for both, primitive.cpp:262-264) */
+PD f3 bsdf_f_pdf(const BSDF &b, const f3 &woW, const f3 &wiW, int flags, float *pdf_out) {
+    *pdf_out = 0.f;
+    if (b.n == 0) return f3(0.f);
+    f3 wi = bsdf_to_local(b, wiW), wo = bsdf_to_local(b, woW);
+    if (is_zero(wo.z)) return f3(0.f);
+    bool refl = dot(wiW, b.ns) * dot(woW, b.ns) > 0;
+    f3 f(0.f);
+    float pdf = 0.f;
+    int matching = 0;
+    for (int i = 0; i < b.n; ++i) {
+        const int ty = lobe_type(b, i);
+        if (!type_matches(ty, flags)) continue;
+        matching += 1;
+        if ((refl && (ty & BSDF_REFLECTION)) || (!refl && (ty & BSDF_TRANSMISSION))) {
+            const LobeFP r = lobe_f_pdf(lobe_load(b, i), wo, wi);
+            f += r.f;
+            pdf += r.pdf;
+        } else pdf += lobe_pdf(lobe_load(b, i), wo, wi);
+    }
+    *pdf_out = matching > 0 ? pdf / matching : 0.f;
+    return f;
+}
 PD f3 bsdf_sample_f(const BSDF &b, const f3 &woW, f3 *wiW, const f2 &u, float *pdf, int type, int *sampledType) {
     int matching = bsdf_num_components(b, type);
     if (matching == 0) { *pdf = 0; *sampledType = 0; return f3(0.f); }
@@ -514,18 +546,27 @@ PD f3 bsdf_sample_f(const BSDF &b, const f3 &woW, f3 *wiW, const f2 &u, float *p
     f3 f = lobe_sample_f(lobe_load(b, picked), wo, &wi, uR, pdf, sampledType);
     if (is_zero(*pdf)) { *sampledType = 0; return f3(0.f); }
     *wiW = bsdf_to_world(b, wi);
-    if (!(ptype & BSDF_SPECULAR) && matching > 1)
-        for (int i = 0; i < b.n; ++i)
-            if (i != picked && type_matches(lobe_type(b, i), type)) *pdf += lobe_pdf(lobe_load(b, i), wo, wi);
-    if (matching > 1) *pdf /= matching;
+    /* reflection.cpp:626-648: the other matching lobes add their density, and f is summed again over all matching lobes
+     * on the side (wo, wi) are on.  The sampled lobe's own term is the value its Sample_f returned - BxDF::f of the same
+     * lobe for the same directions - and a lobe that contributes both f and pdf is evaluated once for both. */
     if (!(ptype & BSDF_SPECULAR)) {
-        bool refl = dot(*wiW, b.ns) * dot(woW, b.ns) > 0;
+        const bool refl = dot(*wiW, b.ns) * dot(woW, b.ns) > 0;
+        const f3 f_picked = f;
         f = f3(0.f);
         for (int i = 0; i < b.n; ++i) {
             const int ty = lobe_type(b, i);
-            if (type_matches(ty, type) && ((refl && (ty & BSDF_REFLECTION)) || (!refl && (ty & BSDF_TRANSMISSION)))) f += lobe_f(lobe_load(b, i), wo, wi);
+            if (!type_matches(ty, type)) continue;
+            const bool side = (refl && (ty & BSDF_REFLECTION)) || (!refl && (ty & BSDF_TRANSMISSION));
+            if (i == picked) {
+                if (side) f += f_picked;
+            } else if (side) {
+                const LobeFP r = lobe_f_pdf(lobe_load(b, i), wo, wi);
+                f += r.f;
+                *pdf += r.pdf;
+            } else *pdf += lobe_pdf(lobe_load(b, i), wo, wi);
         }
     }
+    if (matching > 1) *pdf /= matching;
     return f;
 }
 

@@ -81,8 +81,21 @@ PD f3 ld3(const float *s) { return f3(s[0], s[1], s[2]); }
  * kernel), NeeToPlanes stores each word straight into its plane in HBM (shade kernel: word w of
  * slot s at base[w * cap + s], a coalesced store per field and nothing kept in registers). */
 #define NEE_W(field) ((int)(offsetof(NeeRec, field) / 4))
+/* -DSH_STATS (diagnostic build, tools/gpu_shadestats.py): wave cycles per section of a shaded vertex */
+#ifdef SH_STATS
+enum { SH_LOAD = 0, SH_MEDIUM, SH_MAKE_SI, SH_SCATTER, SH_LIGHT_SAMPLE, SH_BSDF_EVAL, SH_NEE_PUT_A, SH_BSDF_SAMPLE_MIS, SH_LIGHT_PDF, SH_NEE_PUT_B,
+       SH_BSDF_SAMPLE, SH_TAIL, SH_STORE, SH_VERTS, SH_N };
+struct ShStats { long long last; unsigned long long acc[SH_N]; };
+static __device__ unsigned long long g_sh_stats[SH_N];
+#define SH_T(st, k) do { if (!(st)) break; const long long now_ = clock64(); (st)->acc[k] += (unsigned long long)(now_ - (st)->last); (st)->last = now_; } while (0)
+#else
+#define SH_T(st, k) do { } while (0)
+#endif
 struct NeeToStruct {
     NeeRec *r;
+#ifdef SH_STATS
+    ShStats *st = nullptr;
+#endif
     PD void put(int w, float v) const { reinterpret_cast<float *>(r)[w] = v; }
     PD void puti(int w, int v) const { reinterpret_cast<int *>(r)[w] = v; }
     PD void put3(int w, const f3 &v) const { put(w, v.x); put(w + 1, v.y); put(w + 2, v.z); }
@@ -90,6 +103,9 @@ struct NeeToStruct {
 struct NeeToPlanes {
     float *base;
     int slot;
+#ifdef SH_STATS
+    ShStats *st;
+#endif
     PD void put(int w, float v) const { base[plane_at((int)(sizeof(NeeRec) / 4), slot, w)] = v; }
     PD void puti(int w, int v) const { base[plane_at((int)(sizeof(NeeRec) / 4), slot, w)] = __int_as_float(v); }
     PD void put3(int w, const f3 &v) const { put(w, v.x); put(w + 1, v.y); put(w + 2, v.z); }
@@ -123,16 +139,17 @@ PD int build_nee(const DScene &sc, const Ref &it, const BSDF *bsdf, float phase_
     float lightPdf = 0, scatteringPdf = 0;
     LightPoint p1;
     f3 Li = light_sample_li(sc, light, it, uLight, &wi, &lightPdf, &p1);
+    SH_T(rec.st, SH_LIGHT_SAMPLE);
     if (lightPdf > 0 && !is_black(Li) && !is_zero(lightPdf)) {
         f3 f;
         if (bsdf) {
-            f = bsdf_f(*bsdf, it.wo, wi, bsdfFlags) * absdot(wi, it.n);
-            scatteringPdf = bsdf_pdf(*bsdf, it.wo, wi, bsdfFlags);
+            f = bsdf_f_pdf(*bsdf, it.wo, wi, bsdfFlags, &scatteringPdf) * absdot(wi, it.n);
         } else {
             float p = phase_hg(dot(it.wo, wi), phase_g);
             f = f3(p);
             scatteringPdf = p;
         }
+        SH_T(rec.st, SH_BSDF_EVAL);
         if (!is_black(f)) {
             flags |= NEE_A;
             rec.put3(NEE_W(fA), f);
@@ -149,6 +166,7 @@ PD int build_nee(const DScene &sc, const Ref &it, const BSDF *bsdf, float phase_
             rec.put3(NEE_W(p1err), p1.pError);
             rec.put3(NEE_W(p1n), p1.n);
         }
+        SH_T(rec.st, SH_NEE_PUT_A);
     }
     {
         f3 f;
@@ -163,6 +181,7 @@ PD int build_nee(const DScene &sc, const Ref &it, const BSDF *bsdf, float phase_
             f = f3(p);
             scatteringPdf = p;
         }
+        SH_T(rec.st, SH_BSDF_SAMPLE_MIS);
         if (!is_black(f) && scatteringPdf > 0 && !is_zero(scatteringPdf)) {
             float weight = 1;
             bool ok = true;
@@ -171,6 +190,7 @@ PD int build_nee(const DScene &sc, const Ref &it, const BSDF *bsdf, float phase_
                 if (is_zero(lightPdf)) ok = false;
                 else weight = power_heuristic(1, scatteringPdf, 1, lightPdf);
             }
+            SH_T(rec.st, SH_LIGHT_PDF);
             if (ok) {
                 flags |= NEE_B;
                 rec.put3(NEE_W(fB), f);
@@ -183,6 +203,7 @@ PD int build_nee(const DScene &sc, const Ref &it, const BSDF *bsdf, float phase_
             }
         }
     }
+    SH_T(rec.st, SH_NEE_PUT_B);
     if (!(flags & (NEE_A | NEE_B))) return 0;
     if (handleMedium) flags |= NEE_MEDIUM;
     if (countZero) flags |= NEE_COUNT_ZERO;

@@ -145,6 +145,7 @@ PD VertexOut shade_vertex(const DScene &sc, int integrator, Rng &rng, f3 &ro, f3
             scattered_in_medium = true;
         }
     }
+    SH_T(rec.st, SH_MEDIUM);
     if (!scattered_in_medium) {
         if (bounces == 0 || (pflags & PFL_SPECULAR)) {
             if (found) L += beta * surface_le(sc, hp);
@@ -155,7 +156,9 @@ PD VertexOut shade_vertex(const DScene &sc, int integrator, Rng &rng, f3 &ro, f3
         if (pr.flags & PF_EMISSIVE) ctr.light++;
         make_si(sc, hp, hf, ro, rd, ht, ray_medium, &si);
         bsdf_init(&bsdf, si);
+        SH_T(rec.st, SH_MAKE_SI);
         bool scatters = compute_scattering(sc, si, &bsdf, &bp);
+        SH_T(rec.st, SH_SCATTER);
         if (!scatters) return out; /* emitter: its single lobe matches no flag, Sample_f returns pdf 0 */
         Ref it = ref_from_si(si);
         if (bsdf.n == 0) { /* medium boundary without material: pass through, bounce not counted */
@@ -177,7 +180,9 @@ PD VertexOut shade_vertex(const DScene &sc, int integrator, Rng &rng, f3 &ro, f3
         f2 u = rand2(rng);
         f3 wi, wo = -rd;
         int flags = 0;
+        SH_T(rec.st, SH_NEE_PUT_B);
         f3 f = bsdf_sample_f(bsdf, wo, &wi, u, &pdf, BSDF_ALL, &flags);
+        SH_T(rec.st, SH_BSDF_SAMPLE);
         if (is_black(f) || is_zero(pdf)) return out;
         beta *= f * absdot(wi, si.n) / pdf;
         if (flags & BSDF_SPECULAR) pflags |= PFL_SPECULAR;

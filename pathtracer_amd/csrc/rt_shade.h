@@ -23,7 +23,15 @@ k_shade(DScene sc, Pipe pp, PassParams prm, const int *n_ptr, int n_host, const 
     VertexCtr ctr;
     ctr.total = ctr.miss = ctr.surf = ctr.med = ctr.light = ctr.zero = 0;
     unsigned shaded = 0, nee_recs = 0;
+#ifdef SH_STATS
+    ShStats shs;
+    for (int k = 0; k < SH_N; k++) shs.acc[k] = 0;
+#endif
     GRID_STRIDE_BEGIN(n_ptr, n_host)
+#ifdef SH_STATS
+    shs.last = clock64();
+    if (i < n) shs.acc[SH_VERTS] += 1; /* lane 0's count: wave-rounds that had work */
+#endif
     bool alive = false, want_nee = false, want_shadow = false, want_mis = false;
     int slot = 0;
     if (i < n) {
@@ -31,7 +39,11 @@ k_shade(DScene sc, Pipe pp, PassParams prm, const int *n_ptr, int n_host, const 
         int cap = pp.cap;
         PathRec ps;
         soa_load<0, PATH_WORDS>(pp.paths, cap, slot, &ps);
+#ifdef SH_STATS
+        const NeeToPlanes rec = {reinterpret_cast<float *>(pp.nee), slot, &shs};
+#else
         const NeeToPlanes rec = {reinterpret_cast<float *>(pp.nee), slot};
+#endif
         f3 ro(pp.ro[slot], pp.ro[cap + slot], pp.ro[2 * cap + slot]);
         f3 rd(pp.rd[slot], pp.rd[cap + slot], pp.rd[2 * cap + slot]);
         int pixel = pass_pixel(prm, slot);
@@ -40,8 +52,10 @@ k_shade(DScene sc, Pipe pp, PassParams prm, const int *n_ptr, int n_host, const 
         rng.dim = (uint32_t)ps.dim;
         f3 L = ld3(ps.L), beta = ld3(ps.beta);
         int med = ps.medium, bounces = ps.bounces, pflags = ps.flags;
+        SH_T(&shs, SH_LOAD);
         VertexOut vo = shade_vertex<SSS>(sc, prm.integrator, rng, ro, rd, med, pp.hprim[slot], pp.hface[slot], pp.ht[slot], L, beta, bounces,
                                          pflags, rec, ctr, &sss, &s_lobes[threadIdx.x]);
+        SH_T(&shs, SH_TAIL);
         alive = vo.alive;
         want_nee = vo.want_nee;
         shaded++;
@@ -69,7 +83,14 @@ k_shade(DScene sc, Pipe pp, PassParams prm, const int *n_ptr, int n_host, const 
     /* where the vertex goes next is left in its (consumed) hit word; k_route turns these into the four queues.
      * Appending here cost one atomic per wavefront and queue on a single cache line: a third of the kernel. */
     if (i < n) pp.hprim[slot] = (alive ? ROUTE_NEXT : 0) | (want_nee ? ROUTE_NEE : 0) | (want_shadow ? ROUTE_SHADOW : 0) | (want_mis ? ROUTE_MIS : 0);
+#ifdef SH_STATS
+    SH_T(&shs, SH_STORE);
+#endif
     GRID_STRIDE_END
+#ifdef SH_STATS
+    if (__lane_id() == 0)
+        for (int k = 0; k < SH_N; k++) atomicAdd(&g_sh_stats[k], shs.acc[k]);
+#endif
     ctr_flush(ctrs, C_TOTAL, ctr.total);
     ctr_flush(ctrs, C_MISS, ctr.miss);
     ctr_flush(ctrs, C_SURF, ctr.surf);
