@@ -618,11 +618,11 @@ bool decode_pnm(const std::vector<unsigned char> &f, std::vector<unsigned char> 
 } // namespace
 
 /* ---- OpenEXR, the subset environment maps come in ---------------------------------------------------------
- * Single-part scan-line files; compression NONE, RLE, ZIPS, ZIP; HALF, FLOAT or UINT channels; channels R, G,
+ * Single-part scan-line files; compression NONE, RLE, ZIPS, ZIP, PIZ; HALF, FLOAT or UINT channels; channels R, G,
  * B (or one luminance channel, replicated) anywhere in the channel list.  Replaces tinyexr's LoadEXR as the
  * reference uses it (image_util.cpp:21-45): rows top-down in data-window order, Spectrum(R, G, B) per pixel
  * (the reference's Flip(Spectrum(out[it++], out[it++], out[it++])) is R, G, B under g++'s right-to-left
- * evaluation), alpha dropped.  PIZ / PXR24 / B44 / DWA, tiles, deep data and multi-part files are reported. */
+ * evaluation), alpha dropped.  PXR24 / B44 / DWA, tiles, deep data and multi-part files are reported. */
 namespace {
 float half_to_float(uint16_t h) {
     const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
@@ -671,6 +671,196 @@ void exr_unfilter(std::vector<unsigned char> &t, std::vector<unsigned char> &out
         out[i++] = t[a++];
         if (i < t.size()) out[i++] = t[b++];
     }
+}
+/* ---- PIZ (OpenEXR ImfPizCompressor / ImfHuf / ImfWav): a block of up to 32 lines, channel-planar 16-bit words ->
+ * value range compacted through a bitmap -> 2-D Haar-like wavelet per channel (per 16-bit half of a 32-bit channel) ->
+ * canonical Huffman code with a run-length symbol.  Decoding runs the three steps backwards. */
+struct BitReader {
+    const unsigned char *p, *end;
+    uint64_t c = 0;
+    int lc = 0;
+    bool ok = true;
+    BitReader(const unsigned char *b, const unsigned char *e) : p(b), end(e) {}
+    unsigned get(int n) { /* most significant bit first */
+        while (lc < n) {
+            if (p >= end) { ok = false; return 0; }
+            c = (c << 8) | *p++;
+            lc += 8;
+        }
+        lc -= n;
+        return (unsigned)((c >> lc) & ((1ull << n) - 1));
+    }
+};
+bool piz_huf_uncompress(const unsigned char *in, size_t n_in, std::vector<uint16_t> &out, size_t n_out) {
+    out.assign(n_out, 0);
+    if (n_out == 0) return n_in == 0 || n_in >= 20;
+    if (n_in < 20) return false;
+    const uint32_t im = (uint32_t)rd_i32(in), iM = (uint32_t)rd_i32(in + 4), n_bits = (uint32_t)rd_i32(in + 12);
+    const uint32_t ENC = (1u << 16) + 1;
+    if (im >= ENC || iM >= ENC || im > iM) return false;
+    /* the code lengths im .. iM, 6 bits each; 59..62 = a run of 2..5 zero lengths, 63 + 8 bits = a run of 6..261 */
+    std::vector<uint64_t> code(ENC, 0);
+    BitReader tb(in + 20, in + n_in);
+    for (uint32_t i = im; i <= iM; i++) {
+        const unsigned l = tb.get(6);
+        if (!tb.ok) return false;
+        if (l == 63 || l >= 59) {
+            unsigned zerun = l == 63 ? tb.get(8) + 6 : l - 59 + 2;
+            if (!tb.ok || i + zerun > iM + 1) return false;
+            i += zerun - 1; /* the lengths stay 0 */
+        } else code[i] = l;
+    }
+    const unsigned char *data = tb.p; /* the table ends on a byte boundary of what was consumed */
+    if ((size_t)(in + n_in - data) * 8 < n_bits) return false;
+    /* canonical codes: within a length, in symbol order; the longest codes start at 0 */
+    uint64_t n[59] = {};
+    for (uint32_t i = 0; i < ENC; i++) n[code[i]]++;
+    uint64_t c = 0;
+    for (int i = 58; i > 0; --i) {
+        const uint64_t nc = (c + n[i]) >> 1;
+        n[i] = c;
+        c = nc;
+    }
+    uint64_t first[59], count[59] = {};
+    std::vector<uint32_t> sym_at[59];
+    for (int l = 1; l <= 58; l++) first[l] = n[l];
+    for (uint32_t i = 0; i < ENC; i++) {
+        const unsigned l = (unsigned)code[i];
+        if (l > 0) { sym_at[l].push_back(i); count[l]++; }
+    }
+    BitReader br(data, in + n_in);
+    uint64_t left = n_bits;
+    size_t o = 0;
+    const uint32_t rlc = iM;
+    while (left > 0) {
+        uint64_t acc = 0;
+        int l = 0;
+        uint32_t sym = 0;
+        bool found = false;
+        while (l < 58 && left > 0) {
+            acc = (acc << 1) | br.get(1);
+            left--;
+            l++;
+            if (!br.ok) return false;
+            if (count[l] && acc >= first[l] && acc - first[l] < count[l]) { sym = sym_at[l][(size_t)(acc - first[l])]; found = true; break; }
+        }
+        if (!found) { /* trailing pad bits of the last byte */
+            break;
+        }
+        if (sym == rlc) {
+            if (left < 8) return false;
+            const unsigned run = br.get(8);
+            left -= 8;
+            if (!br.ok || o == 0 || o + run > n_out) return false;
+            for (unsigned k = 0; k < run; k++) { out[o] = out[o - 1]; o++; }
+        } else {
+            if (o >= n_out) return false;
+            out[o++] = (uint16_t)sym;
+        }
+    }
+    return o == n_out;
+}
+inline void piz_wdec14(uint16_t l, uint16_t h, uint16_t &a, uint16_t &b) {
+    const short ls = (short)l, hs = (short)h;
+    const int hi = hs, ai = ls + (hi & 1) + (hi >> 1);
+    a = (uint16_t)(short)ai;
+    b = (uint16_t)(short)(ai - hi);
+}
+inline void piz_wdec16(uint16_t l, uint16_t h, uint16_t &a, uint16_t &b) {
+    const int m = l, d = h;
+    const int bb = (m - (d >> 1)) & 0xffff;
+    const int aa = (d + bb - 0x8000) & 0xffff;
+    b = (uint16_t)bb;
+    a = (uint16_t)aa;
+}
+void piz_wav2_decode(uint16_t *in, int nx, int ox, int ny, int oy, uint16_t mx) {
+    const bool w14 = mx < (1 << 14);
+    const int n = nx > ny ? ny : nx;
+    int p = 1, p2;
+    while (p <= n) p <<= 1;
+    p >>= 1;
+    p2 = p;
+    p >>= 1;
+    auto dec = [&](uint16_t l, uint16_t h, uint16_t &a, uint16_t &b) { if (w14) piz_wdec14(l, h, a, b); else piz_wdec16(l, h, a, b); };
+    while (p >= 1) {
+        uint16_t *py = in, *ey = in + (ptrdiff_t)oy * (ny - p2);
+        const ptrdiff_t oy1 = (ptrdiff_t)oy * p, oy2 = (ptrdiff_t)oy * p2, ox1 = (ptrdiff_t)ox * p, ox2 = (ptrdiff_t)ox * p2;
+        uint16_t i00, i01, i10, i11;
+        for (; py <= ey; py += oy2) {
+            uint16_t *px = py, *ex = py + (ptrdiff_t)ox * (nx - p2);
+            for (; px <= ex; px += ox2) {
+                uint16_t *p01 = px + ox1, *p10 = px + oy1, *p11 = p10 + ox1;
+                dec(*px, *p10, i00, i10);
+                dec(*p01, *p11, i01, i11);
+                dec(i00, i01, *px, *p01);
+                dec(i10, i11, *p10, *p11);
+            }
+            if (nx & p) {
+                uint16_t *p10 = px + oy1;
+                dec(*px, *p10, i00, *p10);
+                *px = i00;
+            }
+        }
+        if (ny & p) {
+            uint16_t *px = py, *ex = py + (ptrdiff_t)ox * (nx - p2);
+            for (; px <= ex; px += ox2) {
+                uint16_t *p01 = px + ox1;
+                dec(*px, *p01, i00, *p01);
+                *px = i00;
+            }
+        }
+        p2 = p;
+        p >>= 1;
+    }
+}
+/* one PIZ block -> the raw scan-line layout the other compressions give (line by line, channel by channel) */
+bool exr_unpiz(const unsigned char *src, size_t packed, const std::vector<ExrChannel> &chans, int w, int lines, std::vector<unsigned char> &raw) {
+    if (packed < 4) return false;
+    uint16_t min_nz, max_nz;
+    memcpy(&min_nz, src, 2);
+    memcpy(&max_nz, src + 2, 2);
+    std::vector<unsigned char> bitmap(8192, 0);
+    size_t at = 4;
+    if (max_nz >= 8192) return false;
+    if (min_nz <= max_nz) {
+        const size_t nb = (size_t)max_nz - min_nz + 1;
+        if (at + nb > packed) return false;
+        memcpy(&bitmap[min_nz], src + at, nb);
+        at += nb;
+    }
+    std::vector<uint16_t> lut(65536, 0);
+    unsigned k = 0;
+    for (unsigned i = 0; i < 65536; i++)
+        if (i == 0 || (bitmap[i >> 3] & (1 << (i & 7)))) lut[k++] = (uint16_t)i;
+    const uint16_t max_value = (uint16_t)(k - 1);
+    if (at + 4 > packed) return false;
+    const int32_t len = rd_i32(src + at);
+    at += 4;
+    if (len < 0 || at + (size_t)len > packed) return false;
+    size_t total = 0;
+    std::vector<size_t> start(chans.size());
+    std::vector<int> size(chans.size());
+    for (size_t c = 0; c < chans.size(); c++) {
+        size[c] = chans[c].type == 1 ? 1 : 2;
+        start[c] = total;
+        total += (size_t)w * lines * size[c];
+    }
+    std::vector<uint16_t> buf;
+    if (!piz_huf_uncompress(src + at, (size_t)len, buf, total)) return false;
+    for (size_t c = 0; c < chans.size(); c++)
+        for (int j = 0; j < size[c]; j++) piz_wav2_decode(&buf[start[c] + j], w, size[c], lines, w * size[c], max_value);
+    for (size_t i = 0; i < total; i++) buf[i] = lut[buf[i]];
+    raw.resize(total * 2);
+    size_t o = 0;
+    std::vector<size_t> pos(start);
+    for (int y = 0; y < lines; y++)
+        for (size_t c = 0; c < chans.size(); c++) {
+            const size_t n = (size_t)w * size[c];
+            memcpy(&raw[o], &buf[pos[c]], n * 2);
+            o += n * 2;
+            pos[c] += n;
+        }
+    return true;
 }
 bool exr_fail(const char *path, const char *why) {
     printf("Fail read %s: %s\n", path, why);
@@ -728,7 +918,8 @@ bool exr_decode(const char *path, const std::vector<unsigned char> &f, std::vect
     switch (compression) {
     case 0: case 1: case 2: lines_per_block = 1; break;
     case 3: lines_per_block = 16; break;
-    default: return exr_fail(path, "compression not supported (NONE, RLE, ZIPS and ZIP are)");
+    case 4: lines_per_block = 32; break;
+    default: return exr_fail(path, "compression not supported (NONE, RLE, ZIPS, ZIP and PIZ are)");
     }
     int ci[3] = {-1, -1, -1}, n_colour = 0;
     size_t line_bytes = 0;
@@ -754,16 +945,18 @@ bool exr_decode(const char *path, const std::vector<unsigned char> &f, std::vect
     std::vector<unsigned char> raw, tmp;
     for (int b = 0; b < n_blocks; b++) {
         const uint64_t off = rd_u64(&f[at + 8 * (size_t)b]);
-        if (off + 8 > f.size()) return exr_fail(path, "block offset outside the file");
+        if (off > f.size() || f.size() - off < 8) return exr_fail(path, "block offset outside the file"); /* (off + 8 could wrap) */
         const int y0 = rd_i32(&f[off]) - box[1];
         const int32_t packed = rd_i32(&f[off + 4]);
-        if (y0 < 0 || y0 >= h || packed < 0 || off + 8 + (uint64_t)packed > f.size()) return exr_fail(path, "bad block");
+        if (y0 < 0 || y0 >= h || packed < 0 || (uint64_t)packed > f.size() - off - 8) return exr_fail(path, "bad block");
         const int lines = y0 + lines_per_block <= h ? lines_per_block : h - y0;
         const size_t want = line_bytes * lines;
         const unsigned char *src = &f[off + 8];
         if ((size_t)packed == want || compression == 0) { /* stored as is when packing did not help */
             if ((size_t)packed != want) return exr_fail(path, "bad block size");
             raw.assign(src, src + want);
+        } else if (compression == 4) {
+            if (!exr_unpiz(src, (size_t)packed, chans, w, lines, raw) || raw.size() != want) return exr_fail(path, "bad PIZ block");
         } else if (compression == 1) {
             if (!exr_unrle(src, (size_t)packed, tmp, want)) return exr_fail(path, "bad RLE block");
             exr_unfilter(tmp, raw);

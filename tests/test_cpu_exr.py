@@ -11,8 +11,176 @@ import pytest
 import pathtracer_amd as pa
 from pathtracer_amd import assets, capi
 
-NONE, RLE, ZIPS, ZIP = 0, 1, 2, 3
+NONE, RLE, ZIPS, ZIP, PIZ = 0, 1, 2, 3, 4
 UINT, HALF, FLOAT = 0, 1, 2
+
+
+# ---- an independent PIZ encoder (OpenEXR's published format: range compaction, wavelet, canonical Huffman + run lengths)
+class BitWriter:
+    def __init__(self):
+        self.out, self.c, self.lc, self.bits = bytearray(), 0, 0, 0
+
+    def put(self, n, v):
+        self.c = (self.c << n) | (v & ((1 << n) - 1))
+        self.lc += n
+        self.bits += n
+        while self.lc >= 8:
+            self.lc -= 8
+            self.out.append((self.c >> self.lc) & 0xff)
+        self.c &= (1 << self.lc) - 1
+
+    def flush(self):
+        if self.lc:
+            self.out.append((self.c << (8 - self.lc)) & 0xff)
+            self.c = self.lc = 0
+        return bytes(self.out)
+
+
+def huf_compress(words):
+    import heapq
+    freq = np.bincount(words, minlength=65537).astype(np.int64)
+    nz = np.nonzero(freq)[0]
+    im, iM = int(nz[0]), int(nz[-1]) + 1
+    freq[iM] = 1  # the run-length symbol
+    heap = [(int(freq[i]), i, (i,)) for i in range(im, iM + 1) if freq[i]]
+    length = {h[1]: 0 for h in heap}
+    heapq.heapify(heap)
+    if len(heap) == 1:
+        length[heap[0][1]] = 1
+    while len(heap) > 1:
+        a, b = heapq.heappop(heap), heapq.heappop(heap)
+        for sym in a[2] + b[2]:
+            length[sym] += 1
+        heapq.heappush(heap, (a[0] + b[0], min(a[1], b[1]), a[2] + b[2]))
+    assert max(length.values()) <= 58
+    # canonical codes: the longest first, within a length in symbol order
+    n = [0] * 59
+    for ln in length.values():
+        n[ln] += 1
+    c = 0
+    for i in range(58, 0, -1):
+        n[i], c = c, (c + n[i]) >> 1
+    code = {}
+    for sym in sorted(length):
+        code[sym] = (length[sym], n[length[sym]])
+        n[length[sym]] += 1
+    tb = BitWriter()
+    i = im
+    while i <= iM:
+        ln = length.get(i, 0)
+        if ln == 0:
+            run = 1
+            while i + run <= iM and length.get(i + run, 0) == 0 and run < 261:
+                run += 1
+            if run >= 6:
+                tb.put(6, 63)
+                tb.put(8, run - 6)
+            elif run >= 2:
+                tb.put(6, 59 + run - 2)
+            else:
+                tb.put(6, 0)
+            i += run
+        else:
+            tb.put(6, ln)
+            i += 1
+    table = tb.flush()
+    db = BitWriter()
+    k, nw = 0, len(words)
+    while k < nw:
+        sym = int(words[k])
+        run = 1
+        while k + run < nw and int(words[k + run]) == sym and run < 256:
+            run += 1
+        ls, lr = code[sym][0], code[iM][0]
+        if ls + lr + 8 < ls * (run - 1) + ls:  # symbol + run-length code + count is shorter than repeating the symbol
+            db.put(*code[sym])
+            db.put(*code[iM])
+            db.put(8, run - 1)
+        else:
+            for _ in range(run):
+                db.put(*code[sym])
+        k += run
+    nbits = db.bits
+    data = db.flush()
+    return struct.pack("<IIIII", im, iM, len(table), nbits, 0) + table + data
+
+
+def wav2_encode(a, nx, ox, ny, oy, mx):
+    """in place on the flat int array a (values 0 .. 65535)"""
+    w14 = mx < (1 << 14)
+
+    def s16(v):
+        v &= 0xffff
+        return v - 65536 if v >= 32768 else v
+
+    def enc(x, y):
+        if w14:
+            xs, ys = s16(x), s16(y)
+            return ((xs + ys) >> 1) & 0xffff, (xs - ys) & 0xffff
+        ao = (x + 0x8000) & 0xffff
+        m, d = (ao + y) >> 1, ao - y
+        if d < 0:
+            m = (m + 0x8000) & 0xffff
+        return m, d & 0xffff
+    n = min(nx, ny)
+    p, p2 = 1, 2
+    while p2 <= n:
+        oy1, oy2, ox1, ox2 = oy * p, oy * p2, ox * p, ox * p2
+        py, ey = 0, oy * (ny - p2)
+        while py <= ey:
+            px, ex = py, py + ox * (nx - p2)
+            while px <= ex:
+                p01, p10 = px + ox1, px + oy1
+                p11 = p10 + ox1
+                i00, i01 = enc(a[px], a[p01])
+                i10, i11 = enc(a[p10], a[p11])
+                a[px], a[p10] = enc(i00, i10)
+                a[p01], a[p11] = enc(i01, i11)
+                px += ox2
+            if nx & p:
+                p10 = px + oy1
+                a[px], a[p10] = enc(a[px], a[p10])
+            py += oy2
+        if ny & p:
+            px, ex = py, py + ox * (nx - p2)
+            while px <= ex:
+                p01 = px + ox1
+                a[px], a[p01] = enc(a[px], a[p01])
+                px += ox2
+        p, p2 = p2, p2 << 1
+
+
+def piz_block(rows_per_channel, sizes, w, lines):
+    """rows_per_channel: per channel the block's rows as little-endian 16-bit words [lines, w * size]"""
+    planar = np.concatenate([r.reshape(-1) for r in rows_per_channel]).astype(np.int64)
+    bitmap = np.zeros(8192, np.uint8)
+    vals = np.unique(planar)
+    for v in vals:
+        bitmap[v >> 3] |= 1 << (v & 7)
+    bitmap[0] &= 0xfe  # zero is always in the table
+    nzb = np.nonzero(bitmap)[0]
+    lo, hi = (int(nzb[0]), int(nzb[-1])) if nzb.size else (8191, 0)
+    lut = np.zeros(65536, np.int64)
+    k = 0
+    for i in range(65536):
+        if i == 0 or bitmap[i >> 3] & (1 << (i & 7)):
+            lut[i] = k
+            k += 1
+    mx = k - 1
+    buf = [int(v) for v in lut[planar]]
+    at = 0
+    for size in sizes:
+        for j in range(size):
+            wav2_encode_at(buf, at + j, w, size, lines, w * size, mx)
+        at += w * lines * size
+    huf = huf_compress(np.array(buf, np.int64))
+    return struct.pack("<HH", lo, hi) + (bitmap[lo:hi + 1].tobytes() if lo <= hi else b"") + struct.pack("<i", len(huf)) + huf
+
+
+def wav2_encode_at(buf, start, nx, ox, ny, oy, mx):
+    view = buf[start:]
+    wav2_encode(view, nx, ox, ny, oy, mx)
+    buf[start:] = view
 
 
 def rle(data):
@@ -56,12 +224,17 @@ def write_exr(path, channels, compression, window=(0, 0), decreasing=False):
             attr("dataWindow", "box2i", box) + attr("displayWindow", "box2i", box) + attr("lineOrder", "lineOrder", bytes([1 if decreasing else 0])) +
             attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)) + attr("screenWindowCenter", "v2f", struct.pack("<ff", 0, 0)) +
             attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0")
-    lpb = 16 if compression == ZIP else 1
+    lpb = 16 if compression == ZIP else 32 if compression == PIZ else 1
     dt = {UINT: np.uint32, HALF: np.float16, FLOAT: np.float32}
     blocks = []
     for b0 in range(0, h, lpb):
         raw = b"".join(channels[n][1][y].astype(dt[channels[n][0]]).tobytes() for y in range(b0, min(h, b0 + lpb)) for n in names)
-        if compression == NONE:
+        if compression == PIZ:
+            lines = min(h, b0 + lpb) - b0
+            sizes = [1 if channels[n][0] == HALF else 2 for n in names]
+            rows = [np.stack([np.frombuffer(channels[n][1][y].astype(dt[channels[n][0]]).tobytes(), "<u2") for y in range(b0, b0 + lines)]) for n in names]
+            packed = piz_block(rows, sizes, w, lines)
+        elif compression == NONE:
             packed = raw
         elif compression == RLE:
             packed = rle(filtered(raw))
@@ -89,7 +262,7 @@ def picture(h, w, seed):
     return img
 
 
-@pytest.mark.parametrize("compression", [NONE, RLE, ZIPS, ZIP])
+@pytest.mark.parametrize("compression", [NONE, RLE, ZIPS, ZIP, PIZ])
 @pytest.mark.parametrize("ptype", [HALF, FLOAT])
 def test_exr_round_trip(tmp_path, compression, ptype):
     img = picture(37, 23, compression * 3 + ptype)
@@ -98,6 +271,33 @@ def test_exr_round_trip(tmp_path, compression, ptype):
     got = assets.load_exr(p)
     want = img if ptype == FLOAT else img.astype(np.float16).astype(np.float32)
     assert got.shape == (37, 23, 3) and np.array_equal(got, want)  # bit-exact: half -> float is exact
+
+
+def test_exr_piz_blocks_are_really_piz(tmp_path):
+    """smooth pictures that PIZ does pack (the writer stores a block raw when packing does not help, which would leave the
+    decoder untested): few distinct values (14-bit wavelet), more than 16384 distinct values (16-bit modulo wavelet), odd
+    sizes, a partial last block, mixed channel types, long runs (the run-length symbol)"""
+    h, w = 70, 45  # blocks of 32, 32 and 6 lines
+    y, x = np.mgrid[0:h, 0:w]
+    few = (np.round((np.sin(x / 9.0) + np.cos(y / 7.0)) * 20) / 8).astype(np.float32)
+    flat = np.full((h, w), 0.5, np.float32)
+    flat[10:12, 3:9] = 2.0
+    p = tmp_path / "few.exr"
+    write_exr(p, {"R": (HALF, few), "G": (FLOAT, few * 2), "B": (HALF, flat)}, PIZ)
+    raw_size = h * w * (2 + 4 + 2)
+    assert p.stat().st_size < 0.7 * raw_size
+    got = assets.load_exr(p)
+    assert np.array_equal(got[..., 0], few.astype(np.float16).astype(np.float32)) and np.array_equal(got[..., 1], few * 2)
+    assert np.array_equal(got[..., 2], flat)
+    # > 16384 distinct 16-bit values in one block: a smooth ramp of halves
+    h2, w2 = 33, 700
+    ramp = (1000 + np.arange(h2 * w2)).astype(np.uint16).reshape(h2, w2).view(np.float16)  # consecutive half bit patterns
+    assert np.unique(ramp[:32].view(np.uint16)).size > 16384
+    q = tmp_path / "ramp.exr"
+    write_exr(q, {"Y": (HALF, ramp.astype(np.float32))}, PIZ)
+    assert q.stat().st_size < 0.9 * h2 * w2 * 2
+    got = assets.load_exr(q)
+    assert np.array_equal(got[..., 0], ramp.astype(np.float32))
 
 
 def test_exr_layout_variants(tmp_path):
@@ -133,9 +333,13 @@ def test_exr_failures(tmp_path):
     assert assets.load_exr(tmp_path / "cut.exr") is None
     (tmp_path / "magic.exr").write_bytes(b"PNG!" + data[4:])
     assert assets.load_exr(tmp_path / "magic.exr") is None
-    piz = data.replace(b"compression\0compression\0" + struct.pack("<i", 1) + bytes([ZIP]), b"compression\0compression\0" + struct.pack("<i", 1) + bytes([4]))
+    b44 = data.replace(b"compression\0compression\0" + struct.pack("<i", 1) + bytes([ZIP]), b"compression\0compression\0" + struct.pack("<i", 1) + bytes([6]))
+    (tmp_path / "b44.exr").write_bytes(b44)
+    assert assets.load_exr(tmp_path / "b44.exr") is None  # B44 is reported, not mis-decoded
+    # ZIP data declared as PIZ: the PIZ decoder must refuse it, not crash
+    piz = data.replace(b"compression\0compression\0" + struct.pack("<i", 1) + bytes([ZIP]), b"compression\0compression\0" + struct.pack("<i", 1) + bytes([PIZ]))
     (tmp_path / "piz.exr").write_bytes(piz)
-    assert assets.load_exr(tmp_path / "piz.exr") is None  # PIZ is reported, not mis-decoded
+    assert assets.load_exr(tmp_path / "piz.exr") is None
     tiled = data[:4] + struct.pack("<i", 2 | 0x200) + data[8:]
     (tmp_path / "tiled.exr").write_bytes(tiled)
     assert assets.load_exr(tmp_path / "tiled.exr") is None
