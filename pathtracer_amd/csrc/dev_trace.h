@@ -193,6 +193,9 @@ static __device__ unsigned long long g_pt_stats[PS_N];
 #define PS_CLOCK() 0ll
 #endif
 
+#ifndef PT_PREFETCH
+#define PT_PREFETCH 0
+#endif
 template <class Source, bool COUNT>
 PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *staged, unsigned *total_nodes, unsigned *total_items) {
     int ovf[OVF_STACK];
@@ -217,6 +220,9 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *s
     const int n_rays = src.total();
     int pool_pos = 0, pool_end = 0; /* wave-uniform */
     bool exhausted = false;
+#if PT_PREFETCH
+    int pf_acc = 0, pf_pending = 0; /* the first word of the nearest pushed sibling, loaded one visit ahead of its use */
+#endif
 
 #define PT_FINISH()                                                                  \
     do {                                                                             \
@@ -338,6 +344,14 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *s
             PS_WAVE_IT(PS_IN_IT, PS_IN_LANES);
             int r0, r1, r2, r3;
             const int nh = bvh4_visit_staged(sc.nodes, staged, node, ro, inv, tmax, r0, r1, r2, r3, COUNT ? &rn : nullptr);
+#if PT_PREFETCH
+            pf_acc ^= pf_pending;
+            if (nh > 1) { /* touch the line the pop after this subtree will want: the nearest sibling's node or its first leaf item */
+                const int *pp = r1 >= 0 ? reinterpret_cast<const int *>(sc.nodes + r1)
+                                        : reinterpret_cast<const int *>(sc.items + ((unsigned)(-(r1 + 1)) & 0x07FFFFFFu));
+                pf_pending = __builtin_nontemporal_load(pp);
+            }
+#endif
             if (nh == 0) {
                 if (sp == sp_base) mode = TM_TOPLEAF;
                 else node = PT_POP();
@@ -401,6 +415,9 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *s
         const int ks[] = {PS_OUTER, PS_CYC_REFILL, PS_CYC_TOP, PS_CYC_IN, PS_CYC_LEAF, PS_CYC_TOTAL};
         for (int k : ks) atomicAdd(&g_pt_stats[k], st_[k]);
     }
+#endif
+#if PT_PREFETCH
+    if (pf_acc == 0x5a5a5a5a && n_rays < 0) *total_nodes = (unsigned)pf_acc; /* keeps the touches alive; never taken */
 #endif
 #undef PT_FINISH
 #undef PT_ANY

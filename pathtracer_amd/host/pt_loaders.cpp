@@ -603,7 +603,10 @@ bool decode_pnm(const std::vector<unsigned char> &f, std::vector<unsigned char> 
         if (isspace(f[at])) { at++; continue; }
         if (!isdigit(f[at])) return false;
         int x = 0;
-        while (at < f.size() && isdigit(f[at])) x = x * 10 + (f[at++] - '0');
+        while (at < f.size() && isdigit(f[at])) { /* header values are small: stop growing long before an int could overflow */
+            if (x < 100000000) x = x * 10 + (f[at] - '0');
+            at++;
+        }
         vals[got++] = x;
     }
     if (got < 3 || vals[2] != 255 || at >= f.size()) return false;
@@ -911,9 +914,10 @@ bool exr_decode(const char *path, const std::vector<unsigned char> &f, std::vect
         at += (size_t)size;
     }
     (void)line_order; /* every block carries its y, so the order blocks come in does not matter */
-    w = box[2] - box[0] + 1;
-    h = box[3] - box[1] + 1;
-    if (w <= 0 || h <= 0 || (int64_t)w * h > (1 << 28)) return exr_fail(path, "bad data window");
+    const int64_t w64 = (int64_t)box[2] - box[0] + 1, h64 = (int64_t)box[3] - box[1] + 1; /* the corners are untrusted ints */
+    if (w64 <= 0 || h64 <= 0 || w64 > (1 << 28) || h64 > (1 << 28) || w64 * h64 > (1 << 28)) return exr_fail(path, "bad data window");
+    w = (int)w64;
+    h = (int)h64;
     int lines_per_block;
     switch (compression) {
     case 0: case 1: case 2: lines_per_block = 1; break;
@@ -946,8 +950,9 @@ bool exr_decode(const char *path, const std::vector<unsigned char> &f, std::vect
     for (int b = 0; b < n_blocks; b++) {
         const uint64_t off = rd_u64(&f[at + 8 * (size_t)b]);
         if (off > f.size() || f.size() - off < 8) return exr_fail(path, "block offset outside the file"); /* (off + 8 could wrap) */
-        const int y0 = rd_i32(&f[off]) - box[1];
+        const int64_t y64 = (int64_t)rd_i32(&f[off]) - box[1];
         const int32_t packed = rd_i32(&f[off + 4]);
+        const int y0 = (y64 < 0 || y64 >= h) ? -1 : (int)y64;
         if (y0 < 0 || y0 >= h || packed < 0 || (uint64_t)packed > f.size() - off - 8) return exr_fail(path, "bad block");
         const int lines = y0 + lines_per_block <= h ? lines_per_block : h - y0;
         const size_t want = line_bytes * lines;

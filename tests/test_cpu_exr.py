@@ -340,6 +340,18 @@ def test_exr_failures(tmp_path):
     piz = data.replace(b"compression\0compression\0" + struct.pack("<i", 1) + bytes([ZIP]), b"compression\0compression\0" + struct.pack("<i", 1) + bytes([PIZ]))
     (tmp_path / "piz.exr").write_bytes(piz)
     assert assets.load_exr(tmp_path / "piz.exr") is None
+    # untrusted numbers: a block offset near 2^64 must not wrap past the bounds check; INT_MIN / INT_MAX corners
+    # of the data window and a block y far outside it must be refused without signed overflow
+    table_at = data.index(b"screenWindowWidth\0float\0") + len(b"screenWindowWidth\0float\0") + 4 + 4 + 1
+    assert struct.unpack("<Q", data[table_at:table_at + 8])[0] == table_at + 8  # one ZIP block of 8 lines: the table has one entry
+    (tmp_path / "wrap.exr").write_bytes(data[:table_at] + struct.pack("<Q", 2 ** 64 - 4) + data[table_at + 8:])
+    assert assets.load_exr(tmp_path / "wrap.exr") is None
+    dw = data.index(b"dataWindow\0box2i\0") + len(b"dataWindow\0box2i\0") + 4
+    (tmp_path / "window.exr").write_bytes(data[:dw] + struct.pack("<iiii", -2 ** 31, -2 ** 31, 2 ** 31 - 1, 2 ** 31 - 1) + data[dw + 16:])
+    assert assets.load_exr(tmp_path / "window.exr") is None
+    blk = table_at + 8
+    (tmp_path / "farblock.exr").write_bytes(data[:blk] + struct.pack("<i", -2 ** 31) + data[blk + 4:])
+    assert assets.load_exr(tmp_path / "farblock.exr") is None
     tiled = data[:4] + struct.pack("<i", 2 | 0x200) + data[8:]
     (tmp_path / "tiled.exr").write_bytes(tiled)
     assert assets.load_exr(tmp_path / "tiled.exr") is None
