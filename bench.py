@@ -75,11 +75,11 @@ def measured_traffic(summary, kernel, config):
         return None
 
 
-def classify(c, mis_any):
+def classify(c, mis_any, shadow_closest=False):
     """ray classes from the counters: coherent camera rays; incoherent closest-hit and any-hit scene queries"""
     primary = c["camera_rays"]
-    closest = c["total_paths"] - c["camera_rays"] + c["probe_rays"] + (0 if mis_any else c["mis_rays"])
-    anyhit = c["shadow_rays"] + (c["mis_rays"] if mis_any else 0)
+    closest = c["total_paths"] - c["camera_rays"] + c["probe_rays"] + (0 if mis_any else c["mis_rays"]) + (c["shadow_rays"] if shadow_closest else 0)
+    anyhit = (0 if shadow_closest else c["shadow_rays"]) + (c["mis_rays"] if mis_any else 0)
     return primary, closest, anyhit
 
 
@@ -158,7 +158,13 @@ def main():
     n_parts = sum(fs.clouds[i].n_particles for i in range(fs.n_clouds))
     # Li_VolPath's shadow / MIS rays walk through primitives without a material (emitters, medium boundaries) inside
     # the shade stage's own kernels; otherwise they go through the persistent tracer
-    walks = args.integrator == 3 and any(fs.primitives[i].no_mat or fs.primitives[i].mat.is_emissive for i in range(fs.n_primitives))
+    prims = [fs.primitives[i] for i in range(fs.n_primitives)]
+    bare = any(p.no_mat and not p.mat.is_emissive for p in prims)          # a medium boundary without a material: rays pass through it
+    emitters = any((not p.no_mat) and p.mat.is_emissive for p in prims)
+    nee_closest_ok = os.environ.get("PTR_NEE_CLOSEST", "1") != "0"
+    walks = args.integrator == 3 and (bare or (emitters and not nee_closest_ok))
+    # Li_VolPath, emitters but no bare boundary: a shadow ray is ONE closest-hit query of the persistent tracer (dev_nee.h)
+    shadow_closest = args.integrator == 3 and emitters and not bare and nee_closest_ok
     r = pa.Renderer(local_rank)
     pa.set_bvh_build_mode(args.bvh)
     t_up = time.time()
@@ -227,7 +233,7 @@ def main():
     c = r.counters()
     prof = r.profile()
     mis_any = prof["nee_mis_any"]["launches"] > 0 or (not walks and prof["nee_mis"]["launches"] == 0)
-    primary, sec_closest, sec_any = classify(c, mis_any)
+    primary, sec_closest, sec_any = classify(c, mis_any, shadow_closest)
 
     # roofline leg (untimed, rank 0's GPU only needs it but every rank runs it to stay in step): passes rendered one
     # at a time, so each launch has the GPU to itself - the condition rocprofv3 --kernel-trace measures under (it
@@ -255,10 +261,12 @@ def main():
         # ("trace_closest") and - when they need a closest hit and do not walk - for the MIS rays of direct lighting ("nee_mis")
         mis_closest = 0 if (mis_any or walks) else 1
 
+        sh_closest = 1 if shadow_closest else 0
+
         def closest(p):
-            return (p["trace_closest"]["launches"] + mis_closest * p["nee_mis"]["launches"],
-                    p["trace_closest"]["total_ms"] + mis_closest * p["nee_mis"]["total_ms"])
-        traced = max(1, cc["total_paths"] + mis_closest * cc["mis_rays"])  # counting pass: every bounce is staged, all of them go through the counting variant
+            return (p["trace_closest"]["launches"] + mis_closest * p["nee_mis"]["launches"] + sh_closest * p["nee_shadow"]["launches"],
+                    p["trace_closest"]["total_ms"] + mis_closest * p["nee_mis"]["total_ms"] + sh_closest * p["nee_shadow"]["total_ms"])
+        traced = max(1, cc["total_paths"] + mis_closest * cc["mis_rays"] + sh_closest * cc["shadow_rays"])  # counting pass: every bounce is staged, all of them go through the counting variant
         nodes_per_ray = cc["nodes_visited"] / traced
         items_per_ray = cc["prims_tested"] / traced
         bytes_per_ray = 64.0 + 32.0 * nodes_per_ray + 48.0 * items_per_ray
@@ -266,7 +274,7 @@ def main():
         launches = max(1, launches)
         avg_ms = total_ms / launches
         # rays the tracer launches carried: the segments the finish kernel traces inside itself are not theirs
-        rays_per_launch = (cx["total_paths"] - sx["finish_paths"] + mis_closest * cx["mis_rays"]) / launches
+        rays_per_launch = (cx["total_paths"] - sx["finish_paths"] + mis_closest * cx["mis_rays"] + sh_closest * cx["shadow_rays"]) / launches
         achieved = bytes_per_ray * rays_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         t_launches, t_ms = closest(prof)
         t_avg_ms = t_ms / max(1, t_launches)

@@ -70,6 +70,7 @@ struct __attribute__((aligned(16))) NeeRec {
     /* results of the two queued scene queries (persistent tracer), read by the resolve kernel */
     int occA, hitB;
     float tB;
+    float tA; /* shadow ray traced as a closest-hit ray (occA = primitive or -1): where it ended (SHADOW_CLOSEST below) */
     /* NEE_EXTRA: a term added to L right after this record's (direct light at a BSSRDF exit point) */
     float extra[3];
 };
@@ -326,13 +327,24 @@ PD f3 nee_mis_resolve(const DScene &sc, const NeeRec &rec, NeeCtr &ctr, const La
 /* Both stages for the case where the walks cannot go past their first hit (see nee_shadow): the
  * any-hit result of the shadow ray (rec.occA) and the closest hit of the MIS ray (rec.hitB, rec.tB)
  * were produced by the persistent tracer. */
-PD f3 nee_resolve_traced(const DScene &sc, const NeeRec &rec, NeeCtr &ctr) {
+/* shadow_closest: Li_VolPath in a scene whose only primitives without a material are emitters.  VisibilityTester::Tr
+ * (light.cpp:10-40) then ends at its first hit whatever it is - a material occludes, an emitter ends the walk with the
+ * transmittance up to it - so it is ONE closest-hit query of the persistent tracer: occA = the primitive (or -1), tA = where
+ * the segment ended (the hit, or 1 - ShadowEpsilon). */
+PD f3 nee_resolve_traced(const DScene &sc, const NeeRec &rec, NeeCtr &ctr, bool shadow_closest) {
     f3 Ld(0.f);
     const bool medium = (rec.flags & NEE_MEDIUM) != 0;
     if (rec.flags & NEE_A) {
         f3 Li = ld3(rec.LiA);
         ctr.shadow++;
-        if (rec.occA) Li = f3(0.f);
+        if (shadow_closest) {
+            if (rec.occA >= 0 && sc.prims[rec.occA].material >= 0) Li = f3(0.f);
+            else {
+                f3 Tr(1.f);
+                if (rec.medA >= 0) Tr *= medium_tr(sc.media[rec.medA], ld3(rec.dA), rec.tA);
+                Li *= Tr;
+            }
+        } else if (rec.occA) Li = f3(0.f);
         else if (medium) {
             f3 Tr(1.f);
             if (rec.medA >= 0) Tr *= medium_tr(sc.media[rec.medA], ld3(rec.dA), 1 - kShadowEpsilon);

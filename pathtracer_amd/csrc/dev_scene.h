@@ -28,13 +28,18 @@ struct Node128 {
 /* Node of the top-level BVH over primitives: the reference's own tree (primitive.cpp:537-582),
  * kept because a few results depend on its visiting order.  Leaf: left = -1, handles
  * order[first .. first+n). */
-struct TopNode {
+struct TopNode { /* 96 B = 6 float4; nodes are numbered breadth first (ptr_build.cpp), node 0 is the root */
     float bmin[3];
     int32_t left;
     float bmax[3];
     int32_t right;
     int32_t first, n, pad[2];
+    /* copies of the two children's boxes (inner nodes): one step of the persistent tracer - this node's box, then both
+     * children's - reads one record instead of three (dev_trace.h) */
+    float lmin[3], lmax[3], rmin[3], rmax[3];
 };
+#define TOP_LDS_NODES 64  /* top[0 .. 64) = the upper six levels, kept in LDS by the persistent tracer */
+#define TOP_LDS_ROW 7     /* float4 per staged node: 96 B + 16 B of padding against bank conflicts */
 #define TOP_STACK 48
 #define BVH_NO_CHILD INT32_MIN
 #define BVH_NODE_PREFIX 64 /* nodes[0 .. 64): the upper levels of all geometry trees, breadth first (ptr_build.cpp) */

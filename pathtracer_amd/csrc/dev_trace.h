@@ -177,7 +177,7 @@ struct TwoAny {
  * Per phase: wave iterations, lanes active in them, shader cycles between the phase's first and last instruction. */
 #ifdef PT_STATS
 enum { PS_OUTER = 0, PS_REFILL_IT, PS_REFILL_LANES, PS_TOP_IT, PS_TOP_LANES, PS_IN_IT, PS_IN_LANES, PS_LEAF_IT, PS_LEAF_LANES, PS_LEAF_ENTRY, PS_LEAF_ENTRY_LANES,
-       PS_CYC_REFILL, PS_CYC_TOP, PS_CYC_IN, PS_CYC_LEAF, PS_CYC_TOTAL, PS_RAYS, PS_N };
+       PS_CYC_REFILL, PS_CYC_TOP, PS_CYC_IN, PS_CYC_LEAF, PS_CYC_TOTAL, PS_RAYS, PS_CYC_TOPPRIM, PS_TOPPRIM_IT, PS_TOPPRIM_LANES, PS_N };
 static __device__ unsigned long long g_pt_stats[PS_N];
 #define PS_ADD(k, v) do { st_[k] += (v); } while (0)
 /* inside divergent code: one active lane adds for the wave */
@@ -197,7 +197,8 @@ static __device__ unsigned long long g_pt_stats[PS_N];
 #define PT_PREFETCH 0
 #endif
 template <class Source, bool COUNT>
-PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *staged, unsigned *total_nodes, unsigned *total_items) {
+PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *staged, const float4 *top_staged, unsigned *total_nodes,
+                         unsigned *total_items) {
     int ovf[OVF_STACK];
 #ifdef PT_STATS
     unsigned long long st_[PS_N] = {};
@@ -287,29 +288,37 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *s
             PS_WAVE_IT(PS_TOP_IT, PS_TOP_LANES);
             if (mode == TM_TOP) {
                 if (tnode == -1) { PT_FINISH(); break; }
-                const TopNode &nd = sc.top[tnode];
+                /* one record per step: this node's box and, for an inner node, copies of both children's (TopNode);
+                 * the upper levels come from the block's LDS copy */
+                float4 q0, q1, q2, q3, q4, q5;
+                if (top_staged && tnode < TOP_LDS_NODES) {
+                    const float4 *np = top_staged + tnode * TOP_LDS_ROW;
+                    q0 = np[0]; q1 = np[1]; q2 = np[2]; q3 = np[3]; q4 = np[4]; q5 = np[5];
+                } else {
+                    const float4 *np = reinterpret_cast<const float4 *>(sc.top + tnode);
+                    q0 = np[0]; q1 = np[1]; q2 = np[2]; q3 = np[3]; q4 = np[4]; q5 = np[5];
+                }
+                const int nd_left = __float_as_int(q0.w), nd_right = __float_as_int(q1.w);
                 float te;
                 if (COUNT) rn += 1;
-                if (slab_test(nd.bmin, nd.bmax, ro, inv, tmax, &te)) {
-                    if (nd.left < 0) {
-                        leaf_pos = nd.first;
-                        leaf_end = nd.first + nd.n;
+                if (slab_test6(q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, ro, inv, tmax, &te)) {
+                    if (nd_left < 0) {
+                        leaf_pos = __float_as_int(q2.x);
+                        leaf_end = leaf_pos + __float_as_int(q2.y);
                         mode = TM_TOPLEAF;
                     } else {
-                        const TopNode &l = sc.top[nd.left];
-                        const TopNode &r = sc.top[nd.right];
                         float tl0, tr0;
                         if (COUNT) rn += 2;
-                        bool visitL = slab_test(l.bmin, l.bmax, ro, inv, tmax, &tl0);
-                        bool visitR = slab_test(r.bmin, r.bmax, ro, inv, tmax, &tr0);
+                        bool visitL = slab_test6(q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, ro, inv, tmax, &tl0);
+                        bool visitR = slab_test6(q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, ro, inv, tmax, &tr0);
                         if (visitR && visitL) {
                             int first, second;
-                            if (tr0 < tl0) { first = nd.right; second = nd.left; }
-                            else { first = nd.left; second = nd.right; }
+                            if (tr0 < tl0) { first = nd_right; second = nd_left; }
+                            else { first = nd_left; second = nd_right; }
                             PT_PUSH(second);
                             tnode = first;
-                        } else if (visitL) tnode = nd.left;
-                        else if (visitR) tnode = nd.right;
+                        } else if (visitL) tnode = nd_left;
+                        else if (visitR) tnode = nd_right;
                         else tnode = PT_POP();
                     }
                 } else tnode = PT_POP();
@@ -329,7 +338,15 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *s
                         float t;
                         int face;
                         if (COUNT) ri += 1;
-                        if (shape_hit_t(sc, pr, ro, rd, tmax, &t, &face)) {
+#ifdef PT_STATS
+                        const long long cp0_ = clock64();
+                        PS_WAVE_IT(PS_TOPPRIM_IT, PS_TOPPRIM_LANES);
+#endif
+                        const bool ph_ = shape_hit_t(sc, pr, ro, rd, tmax, &t, &face);
+#ifdef PT_STATS
+                        st_[PS_CYC_TOPPRIM] += clock64() - cp0_;
+#endif
+                        if (ph_) {
                             tmax = t; hp = p; hf = face; hb0 = 0; hb1 = 0; hit = true;
                             if (PT_ANY) { PT_FINISH(); break; }
                         }
@@ -412,7 +429,7 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *s
 #ifdef PT_STATS
     st_[PS_CYC_TOTAL] = clock64() - t_begin_;
     if (lane == 0) {
-        const int ks[] = {PS_OUTER, PS_CYC_REFILL, PS_CYC_TOP, PS_CYC_IN, PS_CYC_LEAF, PS_CYC_TOTAL};
+        const int ks[] = {PS_OUTER, PS_CYC_REFILL, PS_CYC_TOP, PS_CYC_IN, PS_CYC_LEAF, PS_CYC_TOTAL, PS_CYC_TOPPRIM};
         for (int k : ks) atomicAdd(&g_pt_stats[k], st_[k]);
     }
 #endif
@@ -698,10 +715,11 @@ PD void persistent_trace_sched(const DScene &sc, Source src, int *lds, const flo
 #define PT_SCHED 0 /* r02 on config[1]: phases in sequence 190.5 ms per 32-spp pass, fullest-phase-first 193.2 */
 #endif
 template <class Source, bool COUNT>
-PD void persistent_trace_any(const DScene &sc, Source src, int *lds, const float4 *staged, unsigned *total_nodes, unsigned *total_items) {
+PD void persistent_trace_any(const DScene &sc, Source src, int *lds, const float4 *staged, const float4 *top_staged, unsigned *total_nodes,
+                             unsigned *total_items) {
 #if PT_SCHED
     persistent_trace_sched<Source, COUNT>(sc, src, lds, staged, total_nodes, total_items);
 #else
-    persistent_trace<Source, COUNT>(sc, src, lds, staged, total_nodes, total_items);
+    persistent_trace<Source, COUNT>(sc, src, lds, staged, top_staged, total_nodes, total_items);
 #endif
 }

@@ -806,6 +806,29 @@ int ptr_flatten(const PtrFlatScene *fs, HostScene *hs, std::string *err) {
             th[i].prim = (int32_t)i;
         }
         if (!th.empty()) build_top(hs->top, hs->order, th.data(), (int)th.size(), 0, 20, -1);
+        /* The walk only follows left / right / first: renumber the nodes breadth first (the upper levels, which every ray
+         * steps through, become top[0 .. TOP_LDS_NODES)) and give every inner node copies of its children's boxes. */
+        if (!hs->top.empty()) {
+            const size_t nt = hs->top.size();
+            std::vector<int32_t> bfs{0}, new_of(nt, -1);
+            for (size_t head = 0; head < bfs.size(); head++) {
+                const TopNode &nd = hs->top[bfs[head]];
+                if (nd.left >= 0) { bfs.push_back(nd.left); bfs.push_back(nd.right); }
+            }
+            for (size_t k = 0; k < bfs.size(); k++) new_of[bfs[k]] = (int32_t)k;
+            std::vector<TopNode> moved(nt);
+            for (size_t i = 0; i < nt; i++) {
+                TopNode nd = hs->top[i];
+                if (nd.left >= 0) {
+                    const TopNode &l = hs->top[nd.left], &r = hs->top[nd.right];
+                    for (int a = 0; a < 3; a++) { nd.lmin[a] = l.bmin[a]; nd.lmax[a] = l.bmax[a]; nd.rmin[a] = r.bmin[a]; nd.rmax[a] = r.bmax[a]; }
+                    nd.left = new_of[nd.left];
+                    nd.right = new_of[nd.right];
+                }
+                moved[new_of[i]] = nd;
+            }
+            hs->top.swap(moved);
+        }
     }
     return PTR_OK;
 }

@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(TPB) k_route(const int *n_ptr, const int *queu
 
 /* sum of a direct-light record whose two rays went through the persistent tracer */
 __global__ void __launch_bounds__(TPB) k_nee_resolve(DScene sc, Pipe pp, const int *n_ptr, int n_host, const int *queue,
-                                                     unsigned long long *ctrs) {
+                                                     unsigned long long *ctrs, int shadow_closest) {
     NeeCtr ctr;
     ctr.shadow = ctr.mis = ctr.zero = 0;
     GRID_STRIDE_BEGIN(n_ptr, n_host)
@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(TPB) k_nee_resolve(DScene sc, Pipe pp, const i
         NeeRec rec;
         nee_load(pp, slot, &rec);
         soa_load<NEE_RES_BEGIN, NEE_RES_END>(pp.nee, pp.cap, slot, &rec);
-        f3 Ld = nee_resolve_traced(sc, rec, ctr);
+        f3 Ld = nee_resolve_traced(sc, rec, ctr, shadow_closest != 0);
         PathRec ps;
         soa_load<0, 3>(pp.paths, pp.cap, slot, &ps);
         f3 L = ld3(ps.L);
@@ -346,6 +346,7 @@ struct PtrContext {
      * time for a pass that has the GPU to itself, 2 % more when several passes overlap (bench.py): off by default */
     bool merge_traces = false;
     bool nee_one_launch = false; /* shadow + any-hit MIS rays of a bounce in one launch (PTR_NEE_ONE) */
+    bool nee_closest_ok = true; /* PTR_NEE_CLOSEST=0: keep the in-kernel walks wherever a primitive has no material */
     bool mis_any_hit = true; /* MIS rays as any-hit rays where the result cannot tell the difference (PTR_MIS_ANY=0: never) */
     bool scene_has_sss = false; /* some material carries a BSSRDF: k_shade<true> / k_finish<true> */
     /* Which persistent tracer a launch uses.  One ray per lane (dev_trace.h) has the higher throughput once the GPU is full
@@ -535,14 +536,15 @@ static TraceIO path_io(const Lane &l, const int *queue, const int *n_ptr, int n_
     io.counter = cursor;
     return io;
 }
-static TraceIO shadow_io(const Lane &l, const int *queue, const int *n_ptr, int *cursor) { /* any hit within (0, 1 - ShadowEpsilon) */
+/* any hit within (0, 1 - ShadowEpsilon); closest = true: the first hit (primitive into occA, distance into tA) */
+static TraceIO shadow_io(const Lane &l, const int *queue, const int *n_ptr, int *cursor, bool closest = false) {
     TraceIO io;
     memset(&io, 0, sizeof(io));
     io.queue = queue; io.n_ptr = n_ptr;
     io.tile_words = NEE_WORDS;
     io.o = (const char *)l.pipe.nee; io.w_o = WORD_OF(NeeRec, oA); io.w_d = WORD_OF(NeeRec, dA);
     io.tmax_const = 1 - 0.0001f;
-    io.prim = (char *)l.pipe.nee; io.w_prim = WORD_OF(NeeRec, occA); io.w_t = -1;
+    io.prim = (char *)l.pipe.nee; io.w_prim = WORD_OF(NeeRec, occA); io.w_t = closest ? WORD_OF(NeeRec, tA) : -1;
     io.counter = cursor;
     return io;
 }
@@ -590,12 +592,12 @@ static void enqueue_nee_walks(PtrContext *ctx, Lane &l, int n_upper, int cslot) 
         rt_launch_mis_walk(stride_blocks, s, ctx->sc, l.pipe, (const int *)(cnt + 1), 0, (const int *)l.queues[2], ctx->ctrs);
     }
 }
-static void enqueue_resolve(PtrContext *ctx, Lane &l, int n_upper, int cslot) {
+static void enqueue_resolve(PtrContext *ctx, Lane &l, int n_upper, int cslot, bool shadow_closest = false) {
     hipStream_t s = l.stream;
     int *cnt = l.counts + 4 * cslot;
     ProfScope ps(ctx, s, K_RESOLVE, 0);
     hipLaunchKernelGGL(k_nee_resolve, dim3(clampu(nblocks(n_upper), 32, 2048)), dim3(TPB), 0, s, ctx->sc, l.pipe, (const int *)(cnt + 1), 0,
-                       (const int *)l.queues[2], ctx->ctrs);
+                       (const int *)l.queues[2], ctx->ctrs, shadow_closest ? 1 : 0);
 }
 
 /* PTR_DEBUG_SYNC=1: wait for the lane after a stage and report the stage a failure belongs to (a pass queues ~10 launches
@@ -665,10 +667,13 @@ static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int ste
     int qi = 0;
     /* the walks of VisibilityTester::Tr / IntersectTr can only go past their first hit under
      * Li_VolPath and only if some primitive has no material (medium boundary, emitter) */
-    const bool walks = integrator == PTR_LI_VOLPATH && !ctx->scene_all_opaque;
+    /* ... and they go past it only at a bare medium boundary: where every primitive without a material is an emitter, each
+     * walk is one closest-hit query (dev_nee.h nee_resolve_traced), served by the persistent tracer like every other ray */
+    const bool nee_closest = integrator == PTR_LI_VOLPATH && !ctx->scene_all_opaque && !ctx->scene_passthrough && ctx->nee_closest_ok;
+    const bool walks = integrator == PTR_LI_VOLPATH && !ctx->scene_all_opaque && !nee_closest;
     int *cursors = l.counts + 4 * MAX_ITERS; /* ray-fetch cursors of the trace launches, 3 per bounce */
     auto upper_at = [&](int k) { int u = slots >> (k < 6 ? k : 6); return u < 1 ? 1 : u; };
-    if (!walks && ctx->merge_traces) {
+    if (!walks && !nee_closest && ctx->merge_traces) {
         /* per bounce: shade, then ONE trace launch for the rays it made - the next path segments, the
          * shadow rays and the MIS rays - then the direct-light sum (before the next shade adds emission) */
         launch_ptrace(ctx, s, path_io(l, nullptr, nullptr, slots, cursors + 0), slots, false, ctx->count_traversal, K_TRACE);
@@ -711,10 +716,10 @@ static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int ste
                     (use_quad(ctx, 2ll * upper_at(k)) ? rt_launch_qtrace2any : rt_launch_ptrace2any)(trace_blocks(ctx, 2ll * upper_at(k)), s,
                                                                                      ctx->sc, shadow_io(l, l.queues[3], cnt + 2, cursors + 3 * k + 1), mio);
                 } else {
-                launch_ptrace(ctx, s, shadow_io(l, l.queues[3], cnt + 2, cursors + 3 * k + 1), upper_at(k), true, false, K_SHADOW, est[k][1]);
+                launch_ptrace(ctx, s, shadow_io(l, l.queues[3], cnt + 2, cursors + 3 * k + 1, nee_closest), upper_at(k), !nee_closest, nee_closest && ctx->count_traversal, K_SHADOW, est[k][1]);
                 launch_ptrace(ctx, s, mio, upper_at(k), mis_any, ctx->count_traversal, mis_any ? K_MIS_ANY : K_MIS, est[k][2]);
                 }
-                enqueue_resolve(ctx, l, upper_at(k), k);
+                enqueue_resolve(ctx, l, upper_at(k), k, nee_closest);
             }
             STAGE_CHECK("direct light");
             q_cur = q_next;
@@ -812,6 +817,7 @@ int ptr_create(int device, PtrContext **out) {
     if (const char *e = getenv("PTR_NEE_ONE")) ctx->nee_one_launch = atoi(e) != 0;
     if (const char *e = getenv("PTR_STAGE_DIV")) { int v = atoi(e); if (v > 0) ctx->stage_div = v; }
     if (const char *e = getenv("PTR_MIS_ANY")) ctx->mis_any_hit = atoi(e) != 0;
+    if (const char *e = getenv("PTR_NEE_CLOSEST")) ctx->nee_closest_ok = atoi(e) != 0;
     if (const char *e = getenv("PTR_SPREAD")) { /* tuning experiments */
         int v = atoi(e);
         if (v > 0) ctx->spread = v;

@@ -59,7 +59,7 @@ template <int W0, int W1, typename T> PD void soa_store(uint32_t *base, int cap,
 #define NEE_B_BEGIN WORD_OF(NeeRec, fB)
 #define NEE_B_END WORD_OF(NeeRec, occA)
 #define NEE_RES_BEGIN WORD_OF(NeeRec, occA)
-#define NEE_RES_END (WORD_OF(NeeRec, tB) + 1)
+#define NEE_RES_END (WORD_OF(NeeRec, tA) + 1)
 #define NEE_EXTRA_BEGIN WORD_OF(NeeRec, extra)
 #define NEE_EXTRA_END (WORD_OF(NeeRec, extra) + 3)
 PD void nee_load(const Pipe &pp, int slot, NeeRec *rec) { /* header, then only the halves in use */

@@ -13,14 +13,32 @@
 #else
 #define PT_STAGED_NODES(sc) const float4 *s_staged = nullptr
 #endif
+/* top[0 .. TOP_LDS_NODES): the upper levels of the top-level tree (the reference's own, dev_scene.h TopNode), copied to LDS
+ * by every persistent block before its first ray.  PT_LDS_TOPLEVEL=0 compiles the copy out. */
+#ifndef PT_LDS_TOPLEVEL
+#define PT_LDS_TOPLEVEL 1
+#endif
+#if PT_LDS_TOPLEVEL
+#define PT_STAGED_TOP(sc)                                                                         \
+    __shared__ float4 s_top[TOP_LDS_NODES * TOP_LDS_ROW];                                         \
+    {                                                                                             \
+        const int ns_ = sc.n_top < TOP_LDS_NODES ? sc.n_top : TOP_LDS_NODES;                      \
+        const float4 *src_ = reinterpret_cast<const float4 *>(sc.top);                            \
+        for (int i_ = threadIdx.x; i_ < ns_ * 6; i_ += TRACE_TPB) s_top[(i_ / 6) * TOP_LDS_ROW + (i_ % 6)] = src_[i_]; \
+        __syncthreads();                                                                          \
+    }
+#else
+#define PT_STAGED_TOP(sc) const float4 *s_top = nullptr
+#endif
 template <bool ANY, bool COUNT>
 __global__ void __launch_bounds__(TRACE_TPB) __attribute__((amdgpu_waves_per_eu(PT_WAVES, PT_WAVES))) k_ptrace(DScene sc, TraceIO io, unsigned long long *ctrs) {
     __shared__ int s_stack[LDS_STACK * TRACE_TPB];
     PT_STAGED_NODES(sc);
+    PT_STAGED_TOP(sc);
     unsigned tn = 0, ti = 0;
     OneSource<ANY> src;
     src.io = io;
-    persistent_trace_any<OneSource<ANY>, COUNT>(sc, src, &s_stack[threadIdx.x], s_staged, &tn, &ti);
+    persistent_trace_any<OneSource<ANY>, COUNT>(sc, src, &s_stack[threadIdx.x], s_staged, s_top, &tn, &ti);
     if (COUNT) {
         ctr_flush(ctrs, C_NODES, tn);
         ctr_flush(ctrs, C_PRIMS, ti);
@@ -33,12 +51,13 @@ __global__ void __launch_bounds__(TRACE_TPB) __attribute__((amdgpu_waves_per_eu(
 k_ptrace3(DScene sc, TraceIO path, TraceIO shadow, TraceIO mis, unsigned long long *ctrs) {
     __shared__ int s_stack[LDS_STACK * TRACE_TPB];
     PT_STAGED_NODES(sc);
+    PT_STAGED_TOP(sc);
     unsigned tn = 0, ti = 0;
     ThreeSources src;
     src.path = path;
     src.shadow = shadow;
     src.mis = mis;
-    persistent_trace_any<ThreeSources, COUNT>(sc, src, &s_stack[threadIdx.x], s_staged, &tn, &ti);
+    persistent_trace_any<ThreeSources, COUNT>(sc, src, &s_stack[threadIdx.x], s_staged, s_top, &tn, &ti);
     if (COUNT) {
         ctr_flush(ctrs, C_NODES, tn);
         ctr_flush(ctrs, C_PRIMS, ti);
@@ -48,11 +67,12 @@ k_ptrace3(DScene sc, TraceIO path, TraceIO shadow, TraceIO mis, unsigned long lo
 __global__ void __launch_bounds__(TRACE_TPB) __attribute__((amdgpu_waves_per_eu(PT_WAVES, PT_WAVES))) k_ptrace2any(DScene sc, TraceIO a, TraceIO b) {
     __shared__ int s_stack[LDS_STACK * TRACE_TPB];
     PT_STAGED_NODES(sc);
+    PT_STAGED_TOP(sc);
     unsigned tn = 0, ti = 0;
     TwoAny src;
     src.a = a;
     src.b = b;
-    persistent_trace_any<TwoAny, false>(sc, src, &s_stack[threadIdx.x], s_staged, &tn, &ti);
+    persistent_trace_any<TwoAny, false>(sc, src, &s_stack[threadIdx.x], s_staged, s_top, &tn, &ti);
 }
 void rt_launch_ptrace2any(unsigned blocks, hipStream_t s, const DScene &sc, const TraceIO &a, const TraceIO &b) {
     hipLaunchKernelGGL(k_ptrace2any, dim3(blocks), dim3(TRACE_TPB), 0, s, sc, a, b);
