@@ -689,6 +689,11 @@ int ptr_flatten(const PtrFlatScene *fs, HostScene *hs, std::string *err) {
                 DMat m;
                 memset(&m, 0, sizeof(m));
                 m.type = pp.mat.type;
+                {
+                    static const int lobes_of[] = {0, /* matte */ 1, /* mirror */ 1, /* glass */ 2, /* metal */ 1, /* translucent */ 4, /* plastic */ 2,
+                                                   /* uber */ 5, /* subsurface */ 2, /* kdsubsurface */ 2, /* playground */ 1, /* disney */ 5};
+                    if (lobes_of[m.type] > hs->max_lobes) hs->max_lobes = lobes_of[m.type];
+                }
                 m.ntex = pp.mat.n_textures;
                 m.id = pp.mat.id;
                 m.table = -1;

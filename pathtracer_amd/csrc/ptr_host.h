@@ -51,6 +51,7 @@ struct HostScene {
     int view_medium = -1, has_env = 0;
     int bvh_depth = 0;
     bool has_media = false;
+    int max_lobes = 1; /* the most BxDFs any material of the scene pushes (sizes the lobe array of the SSS shade kernel) */
     int bvh_builder = 0;     /* PTR_BVH_HOST_SAH / PTR_BVH_DEVICE_LBVH: who built the geometry trees */
     double bvh_build_ms = 0; /* all geometry trees: host wall time (SAH) or device time (LBVH) */
     /* surface-area estimate of the traversal cost of the largest geometry tree, per ray that enters its root box:

@@ -348,6 +348,7 @@ struct PtrContext {
     bool nee_one_launch = false; /* shadow + any-hit MIS rays of a bounce in one launch (PTR_NEE_ONE) */
     bool nee_closest_ok = true; /* PTR_NEE_CLOSEST=0: keep the in-kernel walks wherever a primitive has no material */
     bool mis_any_hit = true; /* MIS rays as any-hit rays where the result cannot tell the difference (PTR_MIS_ANY=0: never) */
+    int scene_max_lobes = MAX_LOBES;
     bool scene_has_sss = false; /* some material carries a BSSRDF: k_shade<true> / k_finish<true> */
     /* Which persistent tracer a launch uses.  One ray per lane (dev_trace.h) has the higher throughput once the GPU is full
      * (r02, 14.4 M incoherent rays: 3.8 ms against 5.7 ms); four lanes per ray (dev_qtrace.h) has a quarter of the rays in
@@ -571,7 +572,7 @@ static void enqueue_shade(PtrContext *ctx, Lane &l, const PassParams &prm, const
     }
     ProfScope ps(ctx, s, K_SHADE, 0);
     const int walk_i = prm.integrator == PTR_LI_VOLPATH && !ctx->scene_all_opaque ? 1 : 0;
-    const ShadeArgs a = {ctx->sc, l.pipe, prm, hit_count, 0, l.queues[5], q_next, l.queues[2], l.queues[3], l.queues[4], cnt, walk_i, ctx->ctrs};
+    const ShadeArgs a = {ctx->sc, l.pipe, prm, hit_count, 0, l.queues[5], q_next, l.queues[2], l.queues[3], l.queues[4], cnt, walk_i, ctx->scene_max_lobes, ctx->ctrs};
     if (ctx->scene_has_sss) rt_launch_shade_sss(stride_blocks, s, a);
     else rt_launch_shade(stride_blocks, s, a);
     hipLaunchKernelGGL(k_route, dim3(clampu(nblocks((n_upper + ROUTE_CHUNK - 1) / ROUTE_CHUNK), 32, 2048)), dim3(TPB), 0, s, (const int *)hit_count,
@@ -1021,6 +1022,7 @@ int ptr_scene_upload_built(PtrContext *ctx, const PtrBuiltScene *built) {
     ctx->bvh_build = built_info(hs);
     ctx->scene_has_media = hs.has_media;
     ctx->scene_has_sss = !hs.tables.empty();
+    ctx->scene_max_lobes = hs.max_lobes;
     ctx->scene_all_opaque = true;
     ctx->scene_passthrough = false;
     for (const DPrim &pr : hs.prims) {

@@ -128,6 +128,7 @@ struct ShadeArgs {
     const int *queue;
     int *q_next, *q_nee, *q_shadow, *q_mis, *counts;
     int walk;
+    int max_lobes; /* SSS kernel only: lobes of LDS per vertex (the scene's maximum), see rt_shade.h */
     unsigned long long *ctrs;
 };
 struct FinishArgs {

