@@ -3,10 +3,15 @@
  * primitives (medium boundaries, emitters under Li_VolPath): the walks are traversed in-kernel.
  */
 #include "rt_common.h"
+/* The walks are chains of dependent closest-hit traversals, one ray per lane: bound by memory latency, so they want
+ * occupancy more than registers (197 / 220 VGPRs unconstrained = 2 waves/SIMD). */
+#ifndef WALK_WAVES
+#define WALK_WAVES 2
+#endif
 
 /* direct-light stages with the walks of VisibilityTester::Tr / IntersectTr (scenes with medium
  * boundaries or emitters under Li_VolPath) */
-__global__ void __launch_bounds__(TPB) k_shadow_walk(DScene sc, Pipe pp, const int *n_ptr, int n_host, const int *queue,
+__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(WALK_WAVES, WALK_WAVES))) k_shadow_walk(DScene sc, Pipe pp, const int *n_ptr, int n_host, const int *queue,
                                                      unsigned long long *ctrs) {
     __shared__ int s_stack[LDS_STACK * TRACE_TPB];
     LaneStack ls;
@@ -25,7 +30,7 @@ __global__ void __launch_bounds__(TPB) k_shadow_walk(DScene sc, Pipe pp, const i
     ctr_flush(ctrs, C_SHADOW, ctr.shadow);
 }
 
-__global__ void __launch_bounds__(TPB) k_mis_walk(DScene sc, Pipe pp, const int *n_ptr, int n_host, const int *queue,
+__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(WALK_WAVES, WALK_WAVES))) k_mis_walk(DScene sc, Pipe pp, const int *n_ptr, int n_host, const int *queue,
                                                   unsigned long long *ctrs) {
     __shared__ int s_stack[LDS_STACK * TRACE_TPB];
     LaneStack ls;
