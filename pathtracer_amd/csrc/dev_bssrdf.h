@@ -269,9 +269,15 @@ PD float bssrdf_pdf_sp(const Bssrdf &b, const f3 &pi_p, const f3 &pi_n) {
 
 /* The probe chain of Sample_Sp (bssrdf.cpp:511-546): segments from the last hit towards pTarget
  * (Interaction::SpawnRayTo(Point3f), interaction.cpp:12-16: direction = target - p, not offset).
- * Returns how many hits lay on `prim`; with pick >= 0 stops at that hit and fills *out. */
+ * Returns how many hits lay on `prim`; with pick >= 0 stops at that hit and fills *out.
+ * The reference keeps all interactions of the chain in a 39 KB per-thread array and indexes it afterwards; here the
+ * counting walk remembers what the first PROBE_KEEP hits on `prim` were found with (segment, distance, face, medium:
+ * 10 words each) so that the chosen one is rebuilt by make_si from the same inputs - the same interaction, bit for
+ * bit - and only a choice beyond PROBE_KEEP walks the chain a second time (round 1 always did). */
+#define PROBE_KEEP 4
+struct ProbeHit { f3 o, d; float t; int face, med; };
 PD int bssrdf_probe_chain(const DScene &sc, const f3 &start, const f3 &pTarget, int prim, int pick, SI *out, unsigned *probes,
-                          const LaneStack &ls) {
+                          const LaneStack &ls, ProbeHit *keep = nullptr) {
     f3 p = start, pErr(0.f), n(0.f);
     int med_in = -1, med_out = -1;
     int nFound = 0;
@@ -289,6 +295,7 @@ PD int bssrdf_probe_chain(const DScene &sc, const f3 &start, const f3 &pTarget, 
         p = si.p; pErr = si.pError; n = si.n; med_in = si.med_in; med_out = si.med_out;
         if (hp == prim) {
             if (nFound == pick) { *out = si; return nFound + 1; }
+            if (keep && nFound < PROBE_KEEP) { keep[nFound].o = o; keep[nFound].d = d; keep[nFound].t = tmax; keep[nFound].face = hf; keep[nFound].med = med; }
             nFound++;
             if (nFound > PROBE_MAX_FOUND - 1) break;
         }
@@ -313,10 +320,17 @@ PD f3 bssrdf_sample_sp(const DScene &sc, const Bssrdf &b, float u1, const f2 &u2
     float l = 2 * sqrtf(rMax * rMax - r * r);
     f3 start = b.po_p + r * (vx * cosf(phi) + vy * sinf(phi)) - l * vz * 0.5f;
     f3 pTarget = start + l * vz;
-    int nFound = bssrdf_probe_chain(sc, start, pTarget, b.po_prim, -1, pi, probes, ls);
+    ProbeHit keep[PROBE_KEEP];
+    int nFound = bssrdf_probe_chain(sc, start, pTarget, b.po_prim, -1, pi, probes, ls, keep);
     if (nFound == 0) return f3(0.0f);
     int selected = clampi((int)(u1 * nFound), 0, nFound - 1);
-    bssrdf_probe_chain(sc, start, pTarget, b.po_prim, selected, pi, nullptr, ls);
+    if (selected < PROBE_KEEP) {
+        ProbeHit k = keep[0];
+#pragma unroll
+        for (int i = 1; i < PROBE_KEEP; i++)
+            if (selected == i) k = keep[i];
+        make_si(sc, b.po_prim, k.face, k.o, k.d, k.t, k.med, pi);
+    } else bssrdf_probe_chain(sc, start, pTarget, b.po_prim, selected, pi, nullptr, ls);
     *pdf = bssrdf_pdf_sp(b, pi->p, pi->n) / nFound;
     return bssrdf_sr(b, length(b.po_p - pi->p));
 }

@@ -89,8 +89,12 @@ enum { SH_LOAD = 0, SH_MEDIUM, SH_MAKE_SI, SH_SCATTER, SH_LIGHT_SAMPLE, SH_BSDF_
 struct ShStats { long long last; unsigned long long acc[SH_N]; };
 static __device__ unsigned long long g_sh_stats[SH_N];
 #define SH_T(st, k) do { if (!(st)) break; const long long now_ = clock64(); (st)->acc[k] += (unsigned long long)(now_ - (st)->last); (st)->last = now_; } while (0)
+#define SH_STATS_PARAM , ShStats *shs
+#define SH_STATS_ARG , shs
 #else
 #define SH_T(st, k) do { } while (0)
+#define SH_STATS_PARAM
+#define SH_STATS_ARG
 #endif
 struct NeeToStruct {
     NeeRec *r;

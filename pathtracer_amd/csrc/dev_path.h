@@ -19,7 +19,11 @@ struct VertexOut {
     int nee_flags; /* its flags (NEE_A: shadow ray, NEE_B: MIS ray) */
     bool has_extra; /* SSS only: L_extra is to be added to L after the record's own term */
     f3 L_extra;
+    bool defer;     /* SSS_DEFER only: the vertex needs the BSSRDF tail; nothing of it may be stored, the SSS pass redoes it */
 };
+/* shade_vertex's SSS mode: no BSSRDF in the scene / the BSSRDF tail is traversed in place / the tail is left to another
+ * launch (rt_shade.h) */
+enum { SSS_NONE = 0, SSS_INPLACE = 1, SSS_DEFER = 2 };
 
 /* What a kernel that can take the subsurface branch lends to shade_vertex: the BSSRDF probe
  * segment and the direct light at the exit point are traversed in place (dev_bssrdf.h) */
@@ -32,7 +36,7 @@ struct SssCtx {
 
 /* One loop iteration of Li_Direct / Li_Path / Li_PathSampled / Li_VolPath (main.cpp:72-410).
  * On entry (ro, rd) is the ray that was traced and (hp, hf, ht) its closest hit (hp < 0: miss). */
-template <bool SSS, class NeeSink>
+template <int SSS, class NeeSink>
 PD VertexOut shade_vertex(const DScene &sc, int integrator, Rng &rng, f3 &ro, f3 &rd, int &ray_medium, int hp, int hf, float ht, f3 &L,
                           f3 &beta, int &bounces, int &pflags, const NeeSink &rec, VertexCtr &ctr, const SssCtx *sss, float *lobe_mem) {
     VertexOut out;
@@ -41,6 +45,7 @@ PD VertexOut shade_vertex(const DScene &sc, int integrator, Rng &rng, f3 &ro, f3
     out.nee_flags = 0;
     out.has_extra = false;
     out.L_extra = f3(0.f);
+    out.defer = false;
     const bool found = hp >= 0;
     SI si;
     BSDF bsdf;
@@ -191,7 +196,11 @@ PD VertexOut shade_vertex(const DScene &sc, int integrator, Rng &rng, f3 &ro, f3
         ray_medium = ref_medium(it, wi);
         rd = wi;
         if (!vol) ctr.surf++; /* main.cpp:319 counts before the BSSRDF tail, :229 after it */
-        if (SSS && bp.has && (flags & BSDF_TRANSMISSION)) {
+        if (SSS == SSS_DEFER && bp.has && (flags & BSDF_TRANSMISSION)) {
+            out.defer = true;
+            return out;
+        }
+        if (SSS == SSS_INPLACE && bp.has && (flags & BSDF_TRANSMISSION)) {
             out.has_extra = true;
             if (!bssrdf_step(sc, bsdf, bp, si, rng, vol, sss->walk, &out.L_extra, beta, pflags, ro, rd, ray_medium, *sss->nctr, sss->probes, *sss->ls))
                 return out;

@@ -573,8 +573,10 @@ static void enqueue_shade(PtrContext *ctx, Lane &l, const PassParams &prm, const
     ProfScope ps(ctx, s, K_SHADE, 0);
     const int walk_i = prm.integrator == PTR_LI_VOLPATH && !ctx->scene_all_opaque ? 1 : 0;
     const ShadeArgs a = {ctx->sc, l.pipe, prm, hit_count, 0, l.queues[5], q_next, l.queues[2], l.queues[3], l.queues[4], cnt, walk_i, ctx->scene_max_lobes, ctx->ctrs};
-    if (ctx->scene_has_sss) rt_launch_shade_sss(stride_blocks, s, a);
-    else rt_launch_shade(stride_blocks, s, a);
+    if (ctx->scene_has_sss) { /* everything but the BSSRDF tails, then the tails as a dense list (rt_shade.h) */
+        rt_launch_shade_defer(stride_blocks, s, a);
+        rt_launch_shade_sss(clampu(nblocks(n_upper) / 4 + 1, 32, 2048), s, a);
+    } else rt_launch_shade(stride_blocks, s, a);
     hipLaunchKernelGGL(k_route, dim3(clampu(nblocks((n_upper + ROUTE_CHUNK - 1) / ROUTE_CHUNK), 32, 2048)), dim3(TPB), 0, s, (const int *)hit_count,
                        (const int *)l.queues[5], (const int *)l.pipe.hprim, q_next, l.queues[2], l.queues[3], l.queues[4], cnt);
 }

@@ -143,6 +143,7 @@ struct FinishArgs {
 };
 void rt_launch_shade(unsigned blocks, hipStream_t s, const ShadeArgs &a);      /* rt_shade.hip */
 void rt_launch_shade_sss(unsigned blocks, hipStream_t s, const ShadeArgs &a);  /* rt_shade_sss.hip */
+void rt_launch_shade_defer(unsigned blocks, hipStream_t s, const ShadeArgs &a); /* rt_shade_defer.hip */
 void rt_launch_finish(unsigned blocks, hipStream_t s, const FinishArgs &a);     /* rt_finish.hip */
 void rt_launch_finish_sss(unsigned blocks, hipStream_t s, const FinishArgs &a); /* rt_finish_sss.hip */
 void rt_launch_shadow_walk(unsigned blocks, hipStream_t s, const DScene &sc, const Pipe &pp, const int *n_ptr, int n_host, const int *queue,

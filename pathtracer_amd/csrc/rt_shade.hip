@@ -11,4 +11,4 @@ extern "C" int ptr_debug_shade_stats(unsigned long long *out, int n) {
     return 0;
 }
 #endif
-void rt_launch_shade(unsigned blocks, hipStream_t s, const ShadeArgs &a) { rt_launch_shade_t<false>(blocks, s, a); }
+void rt_launch_shade(unsigned blocks, hipStream_t s, const ShadeArgs &a) { rt_launch_shade_t<SSS_NONE>(blocks, s, a); }
