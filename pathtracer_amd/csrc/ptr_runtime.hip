@@ -733,7 +733,7 @@ static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int ste
         const bool walk = integrator == PTR_LI_VOLPATH && !ctx->scene_all_opaque;
         int upper = slots >> (staged < 6 ? staged : 6);
         ProfScope ps(ctx, s, K_FINISH, 0);
-        const FinishArgs a = {ctx->sc, l.pipe, prm, (const int *)(l.counts + 4 * (staged - 1)), 0, q_cur, walk ? 1 : 0, ctx->ctrs};
+        const FinishArgs a = {ctx->sc, l.pipe, prm, (const int *)(l.counts + 4 * (staged - 1)), 0, q_cur, walk ? 1 : 0, ctx->scene_max_lobes, ctx->ctrs};
         const unsigned blocks = clampu(nblocks(upper), 32, 2048);
         if (ctx->scene_has_sss) rt_launch_finish_sss(blocks, s, a);
         else rt_launch_finish(blocks, s, a);

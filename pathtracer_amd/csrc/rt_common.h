@@ -139,6 +139,7 @@ struct FinishArgs {
     int n_host;
     const int *queue;
     int walk;
+    int max_lobes; /* lobes of LDS per path: the scene's maximum (rt_finish.h) */
     unsigned long long *ctrs;
 };
 void rt_launch_shade(unsigned blocks, hipStream_t s, const ShadeArgs &a);      /* rt_shade.hip */

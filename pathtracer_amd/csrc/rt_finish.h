@@ -10,11 +10,17 @@
  * wavefront stages have thinned the pass to a few per cent of its paths: from there on a bounce
  * is worth ~1e4 rays but would still cost three launches that each last as long as their longest
  * ray.  Same device functions, same order of operations per path as the staged kernels. */
+/* Like the BSSRDF tail kernel (rt_shade.h) this one traverses in place, one path per lane, and lives on occupancy: its lobe
+ * array is dynamic LDS sized by the scene's widest material, FINISH_WAVES blocks per CU fit when that leaves room. */
+#ifndef FINISH_WAVES
+#define FINISH_WAVES 2
+#endif
+extern __shared__ float s_dyn_finish_lobes[];
 template <bool SSS>
-__global__ void __launch_bounds__(TPB) k_finish(DScene sc, Pipe pp, PassParams prm, const int *n_ptr, int n_host, const int *queue, int walk,
+__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(FINISH_WAVES, FINISH_WAVES))) k_finish(DScene sc, Pipe pp, PassParams prm, const int *n_ptr, int n_host, const int *queue, int walk,
                                                 unsigned long long *ctrs) {
     __shared__ int s_stack[LDS_STACK * TRACE_TPB];
-    __shared__ float s_lobes[LOBE_LDS_WORDS];
+    float *s_lobes = s_dyn_finish_lobes;
     LaneStack ls;
     ls.lds = &s_stack[threadIdx.x];
     VertexCtr ctr;
@@ -80,5 +86,13 @@ __global__ void __launch_bounds__(TPB) k_finish(DScene sc, Pipe pp, PassParams p
 
 
 template <bool SSS> static void rt_launch_finish_t(unsigned blocks, hipStream_t s, const FinishArgs &a) {
-    hipLaunchKernelGGL(k_finish<SSS>, dim3(blocks), dim3(TPB), 0, s, a.sc, a.pp, a.prm, a.n_ptr, a.n_host, a.queue, a.walk, a.ctrs);
+    const int lobes = a.max_lobes < 1 ? 1 : (a.max_lobes > MAX_LOBES ? MAX_LOBES : a.max_lobes);
+    const size_t dyn = (size_t)lobes * LOBE_WORDS * LOBE_STRIDE * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) { /* more than 64 KB of dynamic LDS has to be asked for */
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_finish<SSS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(MAX_LOBES * LOBE_WORDS * LOBE_STRIDE * sizeof(float)));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_finish<SSS>, dim3(blocks), dim3(TPB), dyn, s, a.sc, a.pp, a.prm, a.n_ptr, a.n_host, a.queue, a.walk, a.ctrs);
 }
