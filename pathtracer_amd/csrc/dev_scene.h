@@ -38,7 +38,9 @@ struct TopNode { /* 96 B = 6 float4; nodes are numbered breadth first (ptr_build
      * children's - reads one record instead of three (dev_trace.h) */
     float lmin[3], lmax[3], rmin[3], rmax[3];
 };
-#define TOP_LDS_NODES 64  /* top[0 .. 64) = the upper six levels, kept in LDS by the persistent tracer */
+#ifndef TOP_LDS_NODES
+#define TOP_LDS_NODES 64 /* top[0 .. 64) = the upper six levels, kept in LDS by the persistent tracer */
+#endif
 #define TOP_LDS_ROW 7     /* float4 per staged node: 96 B + 16 B of padding against bank conflicts */
 #define TOP_STACK 48
 #define BVH_NO_CHILD INT32_MIN
