@@ -171,6 +171,7 @@ HOST_SIGNATURES = {
     "pth_mtl_free": (None, [C.c_void_p]),
     "pth_image_load": (C.c_void_p, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(fptr)]),
     "pth_image_free": (None, [C.c_void_p]),
+    "pth_jpeg_idct": (None, [C.POINTER(C.c_short), C.POINTER(C.c_ubyte)]),
     "pth_exr_read": (C.c_void_p, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pth_exr_free": (None, [C.c_void_p]),
     "pth_make_sky": (None, [C.c_int, C.c_int, C.c_void_p]),

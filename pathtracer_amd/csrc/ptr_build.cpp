@@ -99,6 +99,8 @@ struct Builder {
     int32_t node_base = 0;
     uint32_t item_base = 0;
     static const int NB = 32;
+    float c_trav = 1.0f;  /* SAH: cost of one binary split relative to one item test */
+    size_t always_leaf = 2; /* ranges of at most this many items are leaves without asking the SAH */
 
     Builder(const std::vector<Box> &b, size_t nbase, size_t ibase) : boxes(b), node_base((int32_t)nbase), item_base((uint32_t)ibase) {
         idx.resize(b.size());
@@ -107,6 +109,8 @@ struct Builder {
             idx[i] = (uint32_t)i;
             for (int a = 0; a < 3; a++) cen[3 * i + a] = 0.5f * (b[i].mn[a] + b[i].mx[a]);
         }
+        if (const char *e = getenv("PTR_SAH_CT")) c_trav = (float)atof(e);
+        if (const char *e = getenv("PTR_SAH_ALWAYS_LEAF")) always_leaf = (size_t)atoi(e);
     }
     int32_t make_leaf(size_t lo, size_t hi) {
         uint32_t first = item_base + (uint32_t)order.size(), n = (uint32_t)(hi - lo);
@@ -126,7 +130,7 @@ struct Builder {
         }
         *outBox = bb;
         if (depth > max_depth) max_depth = depth;
-        if (n <= 2) return make_leaf(lo, hi);
+        if (n <= always_leaf) return make_leaf(lo, hi);
 
         size_t mid = 0;
         bool have_split = false;
@@ -170,7 +174,7 @@ struct Builder {
             }
             if (best_axis >= 0) {
                 float parent = bb.half_area();
-                float split_cost = 1.0f + (parent > 0 ? best_cost / parent : (float)n);
+                float split_cost = c_trav + (parent > 0 ? best_cost / parent : (float)n);
                 if (n <= BVH_MAX_LEAF && (float)n <= split_cost) return make_leaf(lo, hi);
                 float ext = cb.mx[best_axis] - cb.mn[best_axis];
                 float scale = NB / ext;

@@ -618,6 +618,584 @@ bool decode_pnm(const std::vector<unsigned char> &f, std::vector<unsigned char> 
     px.assign(f.begin() + at, f.begin() + at + need);
     return true;
 }
+
+/* ---- JPEG (ITU T.81 baseline and progressive Huffman, 8 bit, 1 or 3 components) -----------------------------
+ * Replaces stbi_load(path, &nx, &ny, &nn, 0) of the stb_image the reference vendors (src/third/stb_image.h, v2.0x:
+ * jpeg part :1460-3400) for the two .jpg textures its scenes name (main.cpp:633,635).  A JPEG's pixels are not
+ * defined by the standard to the last bit: they depend on the decoder's inverse DCT, chroma upsampling and colour
+ * conversion.  This decoder is written from the standard, with those three stages in the fixed-point arithmetic
+ * stb_image documents for itself - inverse DCT after jidctint's "islow" factorisation with 12-bit constants and two
+ * guard bits between the passes (:1905-2003), chroma rows / columns interpolated 3:1 for the 2x factors and repeated
+ * for the others (:2848-3038), YCbCr -> RGB with 12-bit constants in a 20-bit fixed point (:3071-3095) - so that a
+ * texture decodes to the bytes the reference renders with.  PARITY UNPINNED: the reference ships neither a .jpg nor
+ * decoded pixels; tests/test_cpu_jpeg.py holds the decoder to Pillow's (libjpeg) within the +-few levels two
+ * correct decoders differ by, and to exact known answers where the arithmetic leaves no freedom.
+ * Like stb_image's: no arithmetic coding, no 12-bit, no CMYK / 4 components, no 16-bit quantisation tables. */
+struct JpegHuff {
+    /* canonical code (T.81 Annex C / F.2.2.3): for each length the first code, its index into `sym`, and the count */
+    int first_code[17], first_sym[17], count[17];
+    unsigned char sym[256];
+    bool defined = false;
+    bool build(const int *counts, const unsigned char *symbols, int n) {
+        int code = 0, k = 0;
+        for (int len = 1; len <= 16; len++) {
+            first_code[len] = code;
+            first_sym[len] = k;
+            count[len] = counts[len - 1];
+            code += counts[len - 1];
+            k += counts[len - 1];
+            if (code > (1 << len)) return false; /* more codes of this length than bits allow */
+            code <<= 1;
+        }
+        if (n > 256) return false;
+        memcpy(sym, symbols, (size_t)n);
+        defined = true;
+        return true;
+    }
+};
+/* entropy-coded segment: bits most significant first, FF00 -> FF, any other FFxx is a marker: it ends the data and
+ * zeros are fed from there on (what stb_image does, :1566-1581) */
+struct JpegBits {
+    const unsigned char *p, *end;
+    uint32_t acc = 0;
+    int n = 0;
+    int marker = -1;
+    JpegBits(const unsigned char *b, const unsigned char *e) : p(b), end(e) {}
+    void reset() { acc = 0; n = 0; marker = -1; }
+    void fill() {
+        while (n <= 24) {
+            int b = 0;
+            if (marker < 0 && p < end) {
+                b = *p++;
+                if (b == 0xff) {
+                    int c = p < end ? *p++ : 0;
+                    if (c != 0) { marker = c; b = 0; }
+                }
+            }
+            if (marker >= 0) b = 0;
+            acc |= (uint32_t)b << (24 - n);
+            n += 8;
+        }
+    }
+    int bits(int k) { /* k <= 16 */
+        if (k == 0) return 0;
+        if (n < k) fill();
+        int v = (int)(acc >> (32 - k));
+        acc <<= k;
+        n -= k;
+        return v;
+    }
+    int bit() { return bits(1); }
+    /* receive + extend (T.81 F.2.2.1): k magnitude bits -> signed value */
+    int receive_extend(int k) {
+        if (k == 0) return 0;
+        int v = bits(k);
+        return v < (1 << (k - 1)) ? v - (1 << k) + 1 : v;
+    }
+    int decode(const JpegHuff &h) { /* -1: no such code */
+        if (n < 16) fill();
+        int code = 0;
+        for (int len = 1; len <= 16; len++) {
+            code = (int)(acc >> (32 - len));
+            int off = code - h.first_code[len];
+            if (off >= 0 && off < h.count[len]) {
+                acc <<= len;
+                n -= len;
+                return h.sym[h.first_sym[len] + off];
+            }
+        }
+        return -1;
+    }
+};
+struct JpegComp {
+    int id = 0, h = 1, v = 1, tq = 0, hd = 0, ha = 0;
+    int px = 0, py = 0;     /* samples this component really has */
+    int w2 = 0, h2 = 0;     /* plane size: whole MCUs */
+    int bw = 0;             /* blocks per plane row */
+    int dc_pred = 0;
+    std::vector<unsigned char> plane;
+    std::vector<int16_t> coef; /* progressive: 64 per block, natural order */
+};
+/* position k of the zig-zag sequence -> row-major index; built once (T.81 figure A.6); beyond 63 a corrupt stream lands on 63 */
+struct JpegZigzag {
+    unsigned char at[64 + 16];
+    JpegZigzag() {
+        int r = 0, c = 0;
+        for (int k = 0; k < 64; k++) {
+            at[k] = (unsigned char)(r * 8 + c);
+            if ((r + c) % 2 == 0) { /* moving up-right */
+                if (c == 7) r++;
+                else if (r == 0) c++;
+                else { r--; c++; }
+            } else { /* moving down-left */
+                if (r == 7) c++;
+                else if (c == 0) r++;
+                else { r++; c--; }
+            }
+        }
+        for (int k = 64; k < 80; k++) at[k] = 63;
+    }
+};
+const JpegZigzag &jpeg_zigzag() { static JpegZigzag z; return z; }
+
+/* one 8-point inverse DCT pass, jidctint's factorisation; constants are round(x * 4096).  in[] are eight samples, the
+ * result is the even part e[0..3] and the odd part o[0..3], both scaled by 4096: out[i] = e[i] + o[3-i], out[7-i] = e[i] - o[3-i].
+ * 32-bit two's-complement arithmetic that wraps (unsigned here, so that a corrupt file's huge coefficients are defined too) */
+typedef uint32_t ju32;
+inline int jpeg_sar(ju32 x, int n) { return (int)((int32_t)x >> n); }
+inline void jpeg_idct8(const int *in, ju32 *e, ju32 *o) {
+    const ju32 K0_541 = 2217, K1_847 = (ju32)-7567, K0_765 = 3135, K1_175 = 4816, K0_298 = 1223, K2_053 = 8410, K3_072 = 12586, K1_501 = 6149,
+               K0_899 = (ju32)-3685, K2_562 = (ju32)-10497, K1_961 = (ju32)-8034, K0_390 = (ju32)-1597;
+    const ju32 s0 = (ju32)in[0], s1 = (ju32)in[1], s2 = (ju32)in[2], s3 = (ju32)in[3], s4 = (ju32)in[4], s5 = (ju32)in[5], s6 = (ju32)in[6], s7 = (ju32)in[7];
+    const ju32 z = (s2 + s6) * K0_541;
+    const ju32 a2 = z + s6 * K1_847, a3 = z + s2 * K0_765;
+    const ju32 a0 = (s0 + s4) * 4096u, a1 = (s0 - s4) * 4096u;
+    e[0] = a0 + a3; e[3] = a0 - a3; e[1] = a1 + a2; e[2] = a1 - a2;
+    const ju32 q3 = s7 + s3, q4 = s5 + s1, q1 = s7 + s1, q2 = s5 + s3;
+    const ju32 q5 = (q3 + q4) * K1_175;
+    const ju32 m1 = q5 + q1 * K0_899, m2 = q5 + q2 * K2_562, m3 = q3 * K1_961, m4 = q4 * K0_390;
+    o[3] = s1 * K1_501 + m1 + m4;
+    o[2] = s3 * K3_072 + m2 + m3;
+    o[1] = s5 * K2_053 + m2 + m4;
+    o[0] = s7 * K0_298 + m1 + m3;
+}
+inline unsigned char jpeg_clamp(int x) { return (unsigned char)(x < 0 ? 0 : (x > 255 ? 255 : x)); }
+/* dequantised coefficients (row-major) -> 8x8 samples.  Columns first, kept with two extra bits; a column whose AC
+ * terms are all zero is its DC term times four (exactly what the full formula gives); then rows, rounded, +128, clamped */
+void jpeg_idct_block(unsigned char *out, int out_stride, const int16_t *d) {
+    int tmp[64];
+    for (int c = 0; c < 8; c++) {
+        int col[8];
+        bool ac = false;
+        for (int r = 0; r < 8; r++) { col[r] = d[r * 8 + c]; if (r && col[r]) ac = true; }
+        if (!ac) {
+            for (int r = 0; r < 8; r++) tmp[r * 8 + c] = col[0] * 4;
+            continue;
+        }
+        ju32 e[4], o[4];
+        jpeg_idct8(col, e, o);
+        for (int i = 0; i < 4; i++) {
+            tmp[i * 8 + c] = jpeg_sar(e[i] + 512u + o[3 - i], 10);
+            tmp[(7 - i) * 8 + c] = jpeg_sar(e[i] + 512u - o[3 - i], 10);
+        }
+    }
+    for (int r = 0; r < 8; r++) {
+        ju32 e[4], o[4];
+        jpeg_idct8(tmp + r * 8, e, o);
+        unsigned char *row = out + (size_t)r * out_stride;
+        const ju32 bias = 65536u + (128u << 17);
+        for (int i = 0; i < 4; i++) {
+            row[i] = jpeg_clamp(jpeg_sar(e[i] + bias + o[3 - i], 17));
+            row[7 - i] = jpeg_clamp(jpeg_sar(e[i] + bias - o[3 - i], 17));
+        }
+    }
+}
+
+struct JpegDecoder {
+    const std::vector<unsigned char> &f;
+    size_t at = 0;
+    int width = 0, height = 0, ncomp = 0;
+    bool progressive = false;
+    int hmax = 1, vmax = 1, mcux = 0, mcuy = 0;
+    int restart_interval = 0;
+    JpegComp comp[3];
+    unsigned char quant[4][64];
+    JpegHuff hdc[4], hac[4];
+    /* the scan being decoded */
+    int scan_n = 0, order[3] = {0, 0, 0}, ss = 0, se = 63, ah = 0, al = 0, eob_run = 0;
+
+    explicit JpegDecoder(const std::vector<unsigned char> &file) : f(file) { memset(quant, 0, sizeof quant); }
+    bool have(size_t n) const { return at + n <= f.size(); }
+    int u8() { return at < f.size() ? f[at++] : 0; }
+    int u16() { int a = u8(); return (a << 8) | u8(); }
+    /* next marker code, skipping fill bytes; -1 at the end of the file or when no FF is where one must be */
+    int next_marker() {
+        if (!have(2) || f[at] != 0xff) return -1;
+        while (at < f.size() && f[at] == 0xff) at++;
+        return at < f.size() ? f[at++] : -1;
+    }
+    bool read_dqt() {
+        int len = u16() - 2;
+        while (len > 0) {
+            int q = u8();
+            if ((q >> 4) != 0 || (q & 15) > 3) return false; /* 8-bit tables only */
+            for (int i = 0; i < 64; i++) quant[q & 15][jpeg_zigzag().at[i]] = (unsigned char)u8();
+            len -= 65;
+        }
+        return len == 0;
+    }
+    bool read_dht() {
+        int len = u16() - 2;
+        while (len > 0) {
+            int q = u8(), counts[16], n = 0;
+            if ((q >> 4) > 1 || (q & 15) > 3) return false;
+            for (int i = 0; i < 16; i++) { counts[i] = u8(); n += counts[i]; }
+            if (n > 256 || !have((size_t)n)) return false;
+            unsigned char symbols[256];
+            for (int i = 0; i < n; i++) symbols[i] = (unsigned char)u8();
+            JpegHuff &h = (q >> 4) ? hac[q & 15] : hdc[q & 15];
+            if (!h.build(counts, symbols, n)) return false;
+            len -= 17 + n;
+        }
+        return len == 0;
+    }
+    bool read_segment(int m) { /* tables and ignorable segments between the frame / scan headers */
+        if (m == 0xdb) return read_dqt();
+        if (m == 0xc4) return read_dht();
+        if (m == 0xdd) {
+            if (u16() != 4) return false;
+            restart_interval = u16();
+            return true;
+        }
+        if ((m >= 0xe0 && m <= 0xef) || m == 0xfe) {
+            int len = u16();
+            if (len < 2 || !have((size_t)len - 2)) return false;
+            at += (size_t)len - 2;
+            return true;
+        }
+        return false;
+    }
+    bool read_frame() {
+        int len = u16();
+        if (len < 11 || u8() != 8) return false;
+        height = u16();
+        width = u16();
+        ncomp = u8();
+        if (height == 0 || width == 0 || (ncomp != 1 && ncomp != 3) || len != 8 + 3 * ncomp) return false;
+        if ((int64_t)width * height > (1 << 28)) return false; /* the PNG route's limit */
+        for (int i = 0; i < ncomp; i++) {
+            JpegComp &c = comp[i];
+            c.id = u8();
+            if (c.id != i + 1 && c.id != i) return false; /* JFIF numbering, or the from-zero numbering some writers use */
+            int q = u8();
+            c.h = q >> 4; c.v = q & 15; c.tq = u8();
+            if (c.h < 1 || c.h > 4 || c.v < 1 || c.v > 4 || c.tq > 3) return false;
+            if (c.h > hmax) hmax = c.h;
+            if (c.v > vmax) vmax = c.v;
+        }
+        mcux = (width + hmax * 8 - 1) / (hmax * 8);
+        mcuy = (height + vmax * 8 - 1) / (vmax * 8);
+        for (int i = 0; i < ncomp; i++) {
+            JpegComp &c = comp[i];
+            c.px = (width * c.h + hmax - 1) / hmax;
+            c.py = (height * c.v + vmax - 1) / vmax;
+            c.w2 = mcux * c.h * 8;
+            c.h2 = mcuy * c.v * 8;
+            c.bw = c.w2 / 8;
+            c.plane.assign((size_t)c.w2 * c.h2, 0);
+            if (progressive) c.coef.assign((size_t)c.w2 * c.h2, 0);
+        }
+        return true;
+    }
+    bool read_scan_header() {
+        int len = u16();
+        scan_n = u8();
+        if (scan_n < 1 || scan_n > ncomp || len != 6 + 2 * scan_n) return false;
+        for (int i = 0; i < scan_n; i++) {
+            int id = u8(), q = u8(), which = 0;
+            while (which < ncomp && comp[which].id != id) which++;
+            if (which == ncomp) return false;
+            comp[which].hd = q >> 4; comp[which].ha = q & 15;
+            if (comp[which].hd > 3 || comp[which].ha > 3) return false;
+            order[i] = which;
+        }
+        ss = u8(); se = u8();
+        int a = u8();
+        ah = a >> 4; al = a & 15;
+        if (progressive) {
+            if (ss > 63 || se > 63 || ss > se || ah > 13 || al > 13) return false;
+        } else {
+            if (ss != 0 || ah != 0 || al != 0) return false;
+            se = 63;
+        }
+        return true;
+    }
+    /* sequential block: DC difference, then (run, size) pairs; coefficients leave dequantised, in 16 bits */
+    bool block_sequential(JpegBits &br, JpegComp &c, int16_t *d) {
+        const unsigned char *zz = jpeg_zigzag().at, *q = quant[c.tq];
+        const JpegHuff &dc = hdc[c.hd], &ac = hac[c.ha];
+        memset(d, 0, 64 * sizeof(int16_t));
+        int t = br.decode(dc);
+        if (t < 0 || t > 16) return false;
+        c.dc_pred = (int)((unsigned)c.dc_pred + (unsigned)br.receive_extend(t)); /* wraps on a corrupt file instead of overflowing */
+        d[0] = (int16_t)((unsigned)c.dc_pred * q[0]);
+        for (int k = 1; k < 64;) {
+            int rs = br.decode(ac);
+            if (rs < 0) return false;
+            int r = rs >> 4, s = rs & 15;
+            if (s == 0) {
+                if (rs != 0xf0) break;
+                k += 16;
+            } else {
+                k += r;
+                int pos = zz[k++];
+                d[pos] = (int16_t)(br.receive_extend(s) * q[pos]);
+            }
+        }
+        return true;
+    }
+    bool block_prog_dc(JpegBits &br, JpegComp &c, int16_t *d) {
+        if (se != 0) return false; /* DC scans carry no AC */
+        if (ah == 0) {
+            memset(d, 0, 64 * sizeof(int16_t));
+            int t = br.decode(hdc[c.hd]);
+            if (t < 0 || t > 16) return false;
+            c.dc_pred = (int)((unsigned)c.dc_pred + (unsigned)br.receive_extend(t));
+            d[0] = (int16_t)((unsigned)c.dc_pred << al);
+        } else if (br.bit()) d[0] = (int16_t)(d[0] + (1 << al));
+        return true;
+    }
+    /* a refinement bit for a coefficient that is already non-zero (T.81 G.1.2.3) */
+    static void refine(JpegBits &br, int16_t *p, int bitv) {
+        if (br.bit() && (*p & bitv) == 0) *p = (int16_t)(*p > 0 ? *p + bitv : *p - bitv);
+    }
+    bool block_prog_ac(JpegBits &br, JpegComp &c, int16_t *d) {
+        if (ss == 0) return false;
+        const unsigned char *zz = jpeg_zigzag().at;
+        const JpegHuff &ac = hac[c.ha];
+        if (ah == 0) { /* first pass over this band */
+            if (eob_run) { eob_run--; return true; }
+            for (int k = ss; k <= se;) {
+                int rs = br.decode(ac);
+                if (rs < 0) return false;
+                int r = rs >> 4, s = rs & 15;
+                if (s == 0) {
+                    if (r < 15) { /* EOBn: this block and 2^r + bits - 1 more end here */
+                        eob_run = (1 << r) - 1;
+                        if (r) eob_run += br.bits(r);
+                        break;
+                    }
+                    k += 16;
+                } else {
+                    k += r;
+                    d[zz[k++]] = (int16_t)((unsigned)br.receive_extend(s) << al);
+                }
+            }
+            return true;
+        }
+        const int bitv = 1 << al;
+        if (eob_run) {
+            eob_run--;
+            for (int k = ss; k <= se; k++) {
+                int16_t *p = &d[zz[k]];
+                if (*p != 0) refine(br, p, bitv);
+            }
+            return true;
+        }
+        int k = ss;
+        do {
+            int rs = br.decode(ac);
+            if (rs < 0) return false;
+            int r = rs >> 4, s = rs & 15, value = 0;
+            if (s == 0) {
+                if (r < 15) {
+                    eob_run = (1 << r) - 1;
+                    if (r) eob_run += br.bits(r);
+                    r = 64; /* nothing new in the rest of the band: only refinements */
+                }
+            } else {
+                if (s != 1) return false;
+                value = br.bit() ? bitv : -bitv;
+            }
+            while (k <= se) { /* skip r zero-valued coefficients, refining the non-zero ones on the way */
+                int16_t *p = &d[zz[k++]];
+                if (*p != 0) refine(br, p, bitv);
+                else {
+                    if (r == 0) { *p = (int16_t)value; break; }
+                    r--;
+                }
+            }
+        } while (k <= se);
+        return true;
+    }
+    bool decode_scan() {
+        JpegBits br(f.data() + at, f.data() + f.size());
+        for (int i = 0; i < ncomp; i++) comp[i].dc_pred = 0;
+        eob_run = 0;
+        int todo = restart_interval ? restart_interval : 0x7fffffff;
+        bool stop = false;
+        /* after each MCU: at a restart interval's end the next marker must be RSTn, else the scan stops there */
+        auto mcu_done = [&]() {
+            if (--todo > 0) return;
+            if (br.n < 24) br.fill();
+            if (br.marker < 0xd0 || br.marker > 0xd7) { stop = true; return; }
+            br.reset();
+            for (int i = 0; i < ncomp; i++) comp[i].dc_pred = 0;
+            eob_run = 0;
+            todo = restart_interval ? restart_interval : 0x7fffffff;
+        };
+        int16_t blk[64];
+        auto one_block = [&](JpegComp &c, int bx, int by) -> bool {
+            if (!progressive) {
+                if (!hdc[c.hd].defined || !hac[c.ha].defined) return false;
+                if (!block_sequential(br, c, blk)) return false;
+                jpeg_idct_block(&c.plane[(size_t)by * 8 * c.w2 + (size_t)bx * 8], c.w2, blk);
+                return true;
+            }
+            int16_t *d = &c.coef[((size_t)by * c.bw + bx) * 64];
+            if (ss == 0) return hdc[c.hd].defined && block_prog_dc(br, c, d);
+            return hac[c.ha].defined && block_prog_ac(br, c, d);
+        };
+        if (scan_n == 1) { /* one component: its blocks in raster order, as many as its real size needs */
+            JpegComp &c = comp[order[0]];
+            const int bw = (c.px + 7) >> 3, bh = (c.py + 7) >> 3;
+            for (int by = 0; by < bh && !stop; by++)
+                for (int bx = 0; bx < bw && !stop; bx++) {
+                    if (!one_block(c, bx, by)) return false;
+                    mcu_done();
+                }
+        } else {
+            if (progressive && ss != 0) return false; /* AC scans are never interleaved */
+            for (int my = 0; my < mcuy && !stop; my++)
+                for (int mx = 0; mx < mcux && !stop; mx++) {
+                    for (int k = 0; k < scan_n; k++) {
+                        JpegComp &c = comp[order[k]];
+                        for (int y = 0; y < c.v; y++)
+                            for (int x = 0; x < c.h; x++)
+                                if (!one_block(c, mx * c.h + x, my * c.v + y)) return false;
+                    }
+                    mcu_done();
+                }
+        }
+        /* where the entropy-coded data ended: the marker the bit reader met, or the next one in the file (zero bytes between
+         * the data and the marker are passed over) */
+        at = (size_t)(br.p - f.data());
+        if (br.marker >= 0) pending = br.marker;
+        else {
+            pending = -1;
+            while (at < f.size()) {
+                int x = f[at++];
+                if (x == 0xff) { pending = at < f.size() ? f[at++] : -1; break; }
+                if (x != 0) return false;
+            }
+        }
+        return true;
+    }
+    int pending = -1; /* marker met at the end of the last scan */
+    void finish_progressive() {
+        for (int i = 0; i < ncomp; i++) {
+            JpegComp &c = comp[i];
+            const int bw = (c.px + 7) >> 3, bh = (c.py + 7) >> 3;
+            const unsigned char *q = quant[c.tq];
+            for (int by = 0; by < bh; by++)
+                for (int bx = 0; bx < bw; bx++) {
+                    int16_t *d = &c.coef[((size_t)by * c.bw + bx) * 64];
+                    for (int k = 0; k < 64; k++) d[k] = (int16_t)(d[k] * q[k]);
+                    jpeg_idct_block(&c.plane[(size_t)by * 8 * c.w2 + (size_t)bx * 8], c.w2, d);
+                }
+        }
+    }
+    bool decode() {
+        if (f.size() < 4 || f[0] != 0xff || f[1] != 0xd8) return false;
+        at = 2;
+        int m = next_marker();
+        while (m != 0xc0 && m != 0xc1 && m != 0xc2) {
+            if (m < 0 || !read_segment(m)) return false;
+            m = next_marker();
+            while (m < 0 && at < f.size()) { at++; m = next_marker(); } /* padding after a segment */
+        }
+        progressive = m == 0xc2;
+        if (!read_frame()) return false;
+        m = next_marker();
+        while (m != 0xd9) {
+            if (m == 0xda) {
+                if (!read_scan_header() || !decode_scan()) return false;
+                m = pending;
+                if (m < 0) return false;
+                continue;
+            }
+            if (m < 0 || !read_segment(m)) return false;
+            m = next_marker();
+        }
+        if (progressive) finish_progressive();
+        return true;
+    }
+};
+
+/* one output row of a component at full width: chroma interpolated 3:1 between the nearer and the farther source row /
+ * column for the factor-2 cases (centred, JFIF siting), samples repeated otherwise */
+const unsigned char *jpeg_upsample_row(unsigned char *out, const unsigned char *near_row, const unsigned char *far_row, int w, int hs, int vs) {
+    if (hs == 1 && vs == 1) return near_row;
+    if (hs == 1 && vs == 2) {
+        for (int i = 0; i < w; i++) out[i] = (unsigned char)((3 * near_row[i] + far_row[i] + 2) >> 2);
+        return out;
+    }
+    if (hs == 2 && vs == 1) {
+        const unsigned char *in = near_row;
+        if (w == 1) { out[0] = out[1] = in[0]; return out; }
+        out[0] = in[0];
+        out[1] = (unsigned char)((in[0] * 3 + in[1] + 2) >> 2);
+        for (int i = 1; i < w - 1; i++) {
+            out[2 * i] = (unsigned char)((3 * in[i] + in[i - 1] + 2) >> 2);
+            out[2 * i + 1] = (unsigned char)((3 * in[i] + in[i + 1] + 2) >> 2);
+        }
+        out[2 * (w - 1)] = (unsigned char)((in[w - 2] + 3 * in[w - 1] + 2) >> 2);
+        out[2 * (w - 1) + 1] = in[w - 1];
+        return out;
+    }
+    if (hs == 2 && vs == 2) { /* vertical 3:1 first (kept times four), then horizontal 3:1: sixteenths */
+        int cur = 3 * near_row[0] + far_row[0];
+        if (w == 1) { out[0] = out[1] = (unsigned char)((cur + 2) >> 2); return out; }
+        out[0] = (unsigned char)((cur + 2) >> 2);
+        for (int i = 1; i < w; i++) {
+            const int prev = cur;
+            cur = 3 * near_row[i] + far_row[i];
+            out[2 * i - 1] = (unsigned char)((3 * prev + cur + 8) >> 4);
+            out[2 * i] = (unsigned char)((3 * cur + prev + 8) >> 4);
+        }
+        out[2 * w - 1] = (unsigned char)((cur + 2) >> 2);
+        return out;
+    }
+    for (int i = 0; i < w; i++)
+        for (int j = 0; j < hs; j++) out[i * hs + j] = near_row[i];
+    return out;
+}
+
+/* JPEG -> rows top-down, 1 (greyscale file) or 3 interleaved channels: stbi_load(..., 0) */
+bool decode_jpeg(const std::vector<unsigned char> &f, std::vector<unsigned char> &px, int &w, int &h, int &nn) {
+    if (f.size() < 4 || f[0] != 0xff || f[1] != 0xd8) return false;
+    JpegDecoder z(f);
+    if (!z.decode()) return false;
+    w = z.width; h = z.height; nn = z.ncomp;
+    px.assign((size_t)w * h * nn, 0);
+    struct Up { int hs, vs, w_lores, ystep, ypos; const unsigned char *line0, *line1; std::vector<unsigned char> buf; } up[3];
+    for (int k = 0; k < nn; k++) {
+        Up &r = up[k];
+        r.hs = z.hmax / z.comp[k].h;
+        r.vs = z.vmax / z.comp[k].v;
+        r.ystep = r.vs >> 1;
+        r.w_lores = (w + r.hs - 1) / r.hs;
+        r.ypos = 0;
+        r.line0 = r.line1 = z.comp[k].plane.data();
+        r.buf.assign((size_t)w + 8, 0);
+    }
+    const int CR_R = 5743 << 8, CR_G = -(2925 << 8), CB_G = -(1410 << 8), CB_B = 7258 << 8; /* round(x * 4096) << 8 of 1.402, 0.71414, 0.34414, 1.772 */
+    for (int j = 0; j < h; j++) {
+        const unsigned char *row[3] = {nullptr, nullptr, nullptr};
+        for (int k = 0; k < nn; k++) {
+            Up &r = up[k];
+            const bool lower = r.ystep >= (r.vs >> 1); /* the output row lies in the lower half of its source row: the next one is the nearer */
+            row[k] = jpeg_upsample_row(r.buf.data(), lower ? r.line1 : r.line0, lower ? r.line0 : r.line1, r.w_lores, r.hs, r.vs);
+            if (++r.ystep >= r.vs) {
+                r.ystep = 0;
+                r.line0 = r.line1;
+                if (++r.ypos < z.comp[k].py) r.line1 += z.comp[k].w2;
+            }
+        }
+        unsigned char *out = &px[(size_t)j * w * nn];
+        if (nn == 1) { memcpy(out, row[0], (size_t)w); continue; }
+        for (int i = 0; i < w; i++) {
+            const int yf = (row[0][i] << 20) + (1 << 19), cb = row[1][i] - 128, cr = row[2][i] - 128;
+            int r = yf + cr * CR_R;
+            int g = yf + cr * CR_G + (int)((unsigned)(cb * CB_G) & 0xffff0000u);
+            int b = yf + cb * CB_B;
+            out[3 * i] = jpeg_clamp(r >> 20);
+            out[3 * i + 1] = jpeg_clamp(g >> 20);
+            out[3 * i + 2] = jpeg_clamp(b >> 20);
+        }
+    }
+    return true;
+}
 } // namespace
 
 /* ---- OpenEXR, the subset environment maps come in ---------------------------------------------------------
@@ -1019,8 +1597,8 @@ ImageData *LoadTextureImageData(const char *path) {
         printf("Could not open image %s\n", path);
         return nullptr;
     }
-    if (!decode_png(file, px, nx, ny, nn) && !decode_pnm(file, px, nx, ny, nn)) {
-        printf("No decoder for image %s (PNG 8-bit non-interlaced and binary PGM/PPM are supported)\n", path);
+    if (!decode_png(file, px, nx, ny, nn) && !decode_jpeg(file, px, nx, ny, nn) && !decode_pnm(file, px, nx, ny, nn)) {
+        printf("No decoder for image %s (PNG 8-bit non-interlaced, JPEG baseline / progressive 8-bit and binary PGM/PPM are supported)\n", path);
         return nullptr;
     }
     ImageData *img = new ImageData();
@@ -1237,6 +1815,8 @@ void *pth_image_load(const char *path, int *width, int *height, const float **rg
     *width = img->width; *height = img->height; *rgb = (const float *)img->data;
     return img;
 }
+/* unit hook for tests: the JPEG decoder's inverse DCT on one block of dequantised coefficients (row-major) -> 64 samples */
+void pth_jpeg_idct(const short *coef, unsigned char *out) { jpeg_idct_block(out, 8, (const int16_t *)coef); }
 /* ReadImageEXR: width*height*3 floats the caller releases with pth_exr_free */
 const float *pth_exr_read(const char *path, int *width, int *height) { return (const float *)ReadImageEXR(path, *width, *height); }
 void pth_exr_free(const float *p) { delete[] (Spectrum *)p; }
