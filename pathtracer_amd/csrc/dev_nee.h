@@ -102,6 +102,7 @@ struct NeeToStruct {
     ShStats *st = nullptr;
 #endif
     PD void put(int w, float v) const { reinterpret_cast<float *>(r)[w] = v; }
+    void put(int w, int v) const = delete; /* an index stored through put() would be converted to float: medium 1 -> 0x3f800000 */
     PD void puti(int w, int v) const { reinterpret_cast<int *>(r)[w] = v; }
     PD void put3(int w, const f3 &v) const { put(w, v.x); put(w + 1, v.y); put(w + 2, v.z); }
 };
@@ -112,6 +113,7 @@ struct NeeToPlanes {
     ShStats *st;
 #endif
     PD void put(int w, float v) const { base[plane_at((int)(sizeof(NeeRec) / 4), slot, w)] = v; }
+    void put(int w, int v) const = delete;
     PD void puti(int w, int v) const { base[plane_at((int)(sizeof(NeeRec) / 4), slot, w)] = __int_as_float(v); }
     PD void put3(int w, const f3 &v) const { put(w, v.x); put(w + 1, v.y); put(w + 2, v.z); }
 };
@@ -203,7 +205,7 @@ PD int build_nee(const DScene &sc, const Ref &it, const BSDF *bsdf, float phase_
                 rec.put(NEE_W(pdfB), scatteringPdf);
                 rec.put3(NEE_W(oB), offset_ray_origin(it.p, it.pError, it.n, wi));
                 rec.put3(NEE_W(dB), wi);
-                rec.put(NEE_W(medB), ref_medium(it, wi));
+                rec.puti(NEE_W(medB), ref_medium(it, wi));
                 rec.puti(NEE_W(light), lightNum);
             }
         }

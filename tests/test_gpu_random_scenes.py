@@ -1,0 +1,198 @@
+"""Randomly assembled scenes, HIP path against the oracle through the C-ABI.
+
+The scene catalogue of the parity tests (tests/common.py) holds the reference's own scene families; this file draws
+what they do not combine: every shape type under random rotations / translations, every material type with random
+parameters on any shape, meshes and particle clouds next to analytic and SDF primitives, one to three emitters of
+different shapes, optionally a medium inside a material-less boundary (the in-kernel direct-light walks of Li_VolPath)
+or a glass shell around a medium, optionally fog at the camera.  Seeds are fixed: a failure names its scene.
+Checked per scene: closest hit on camera-like and random rays (ids on non-tied rays, t bit-exact), any hit, and the
+image of all four integrators with the loose catalogue-wide bounds."""
+import numpy as np
+import pytest
+
+import pathtracer_amd as pa
+from oracle import orc
+from pathtracer_amd import scene as S
+
+import common
+
+pytestmark = pytest.mark.gpu
+FMAX = np.finfo(np.float32).max
+W, H, SPP, SEED = 64, 48, 8, 11
+
+
+def rand_color(rng, lo=0.1, hi=0.9):
+    return tuple(float(v) for v in rng.uniform(lo, hi, 3))
+
+
+def rand_material(rng):
+    kind = rng.choice(["matte", "matte_rough", "mirror", "glass", "glass_rough", "metal", "plastic", "uber", "translucent", "disney"])
+    if kind == "matte":
+        return pa.material("matte", kd=rand_color(rng))
+    if kind == "matte_rough":
+        return pa.material("matte", kd=rand_color(rng), sigma=float(rng.uniform(5, 60)))
+    if kind == "mirror":
+        return pa.material("mirror", kr=rand_color(rng, 0.5, 0.95))
+    if kind == "glass":
+        return pa.material("glass", index=float(rng.uniform(1.2, 1.8)))
+    if kind == "glass_rough":
+        return pa.material("glass", kr=rand_color(rng, 0.6, 1), kt=rand_color(rng, 0.6, 1), uroughness=float(rng.uniform(0.02, 0.4)),
+                           vroughness=float(rng.uniform(0.02, 0.4)), index=float(rng.uniform(1.2, 1.8)))
+    if kind == "metal":
+        return pa.material("metal", uroughness=float(rng.uniform(0.01, 0.3)), vroughness=float(rng.uniform(0.01, 0.3)))
+    if kind == "plastic":
+        return pa.material("plastic", kd=rand_color(rng), ks=rand_color(rng, 0.05, 0.5), roughness=float(rng.uniform(0.02, 0.5)))
+    if kind == "uber":
+        return pa.material("uber", kd=rand_color(rng), ks=rand_color(rng, 0.05, 0.4), kr=rand_color(rng, 0, 0.3), kt=rand_color(rng, 0, 0.3),
+                           uroughness=float(rng.uniform(0.05, 0.4)), vroughness=float(rng.uniform(0.05, 0.4)),
+                           opacity=rand_color(rng, 0.5, 1.0), eta=float(rng.uniform(1.2, 1.7)))
+    if kind == "translucent":
+        return pa.material("translucent", kd=rand_color(rng), ks=rand_color(rng, 0.05, 0.4), reflect=rand_color(rng, 0.2, 0.8),
+                           transmit=rand_color(rng, 0.2, 0.8), roughness=float(rng.uniform(0.05, 0.5)))
+    return pa.material("disney", color=rand_color(rng), roughness=float(rng.uniform(0.1, 0.9)), sheen=float(rng.uniform(0, 1)),
+                       sheen_tint=float(rng.uniform(0, 1)), clearcoat=float(rng.uniform(0, 1)), clearcoat_gloss=float(rng.uniform(0.2, 1)),
+                       flatness=float(rng.uniform(0, 1)))
+
+
+def rand_pose(rng, spread=2.0):
+    t = rng.uniform(-spread, spread, 3)
+    return S.translate(*t) @ S.rotate_y(float(rng.uniform(0, 360))) @ S.rotate_x(float(rng.uniform(0, 360)))
+
+
+def bumpy_grid(rng, n):
+    """an n x n grid of quads with displaced vertices: 2 n^2 triangles"""
+    u = np.linspace(-1, 1, n + 1)
+    x, y = np.meshgrid(u, u)
+    z = 0.25 * np.sin(3 * x + rng.uniform(0, 6)) * np.cos(2 * y + rng.uniform(0, 6)) + rng.normal(0, 0.02, x.shape)
+    v = np.stack([x.ravel(), y.ravel(), z.ravel()], 1).astype(np.float32)
+    i = np.arange(n * n)
+    a = (i // n) * (n + 1) + i % n
+    tri = np.concatenate([np.stack([a, a + 1, a + n + 2], 1), np.stack([a, a + n + 2, a + n + 1], 1)]).astype(np.int32)
+    return v, tri
+
+
+def add_shape(b, rng, mat, **kw):
+    kind = rng.choice(["sphere", "rectangle", "disk", "box", "sphere_procedural", "mesh", "cloud"])
+    pose = rand_pose(rng)
+    if kind == "sphere":
+        return b.sphere(float(rng.uniform(0.3, 0.9)), mat, pose, **kw)
+    if kind == "rectangle":
+        return b.rectangle(float(rng.uniform(0.6, 2.5)), float(rng.uniform(0.6, 2.5)), mat, pose, **kw)
+    if kind == "disk":
+        return b.disk(0.0, float(rng.uniform(0.5, 1.2)), float(rng.choice([0.0, 0.2])), 360.0, mat, pose, **kw)
+    if kind == "box":
+        return b.box(float(rng.uniform(0.3, 0.9)), float(rng.uniform(0.3, 0.9)), float(rng.uniform(0.3, 0.9)), mat, pose, **kw)
+    if kind == "sphere_procedural":
+        return b.sphere_procedural(float(rng.uniform(0.3, 0.8)), mat, pose, **kw)
+    if kind == "mesh":
+        v, t = bumpy_grid(rng, int(rng.integers(3, 14)))
+        return b.mesh(v, t, mat, pose, **kw)
+    n = int(rng.integers(20, 400))
+    pos = (rng.normal(0, 0.5, (n, 3)) + rng.uniform(-1.5, 1.5, 3)).astype(np.float32)
+    return b.cloud(pos, float(rng.uniform(0.03, 0.12)), mat, **kw)
+
+
+def random_scene(seed):
+    rng = np.random.default_rng(1000 + seed)
+    b = pa.FlatSceneBuilder()
+    # a floor, so that most paths have somewhere to go
+    b.rectangle(9.0, 9.0, pa.material("matte", kd=rand_color(rng, 0.4, 0.8)), S.translate(0, -2.2, 0) @ S.rotate_x(90))
+    for _ in range(int(rng.integers(3, 8))):
+        add_shape(b, rng, rand_material(rng))
+    # emitters: a panel overhead always, sometimes a ball or a disk among the objects
+    px, pz = rng.uniform(-1, 1, 2)
+    b.rectangle(2.0, 2.0, pa.material("emissive", L=rand_color(rng, 4, 12)), S.translate(px, 3.2, pz) @ S.rotate_x(90))
+    extra = rng.integers(0, 3)
+    if extra >= 1:
+        b.sphere(float(rng.uniform(0.15, 0.4)), pa.material("emissive", L=rand_color(rng, 5, 20)), S.translate(*rng.uniform(-2, 2, 3)))
+    if extra == 2:
+        b.disk(0.0, float(rng.uniform(0.3, 0.7)), 0.0, 360.0, pa.material("emissive", L=rand_color(rng, 5, 20)), rand_pose(rng))
+    # media: seed % 3 == 1: a medium inside a boundary without material; == 2: inside a glass ball; every fourth scene: fog at the camera
+    mode = seed % 3
+    if mode == 1:
+        med = pa.medium(rand_color(rng, 0.05, 0.6), rand_color(rng, 0.2, 1.5), float(rng.uniform(-0.6, 0.8)))
+        b.sphere(float(rng.uniform(0.6, 1.1)), None, S.translate(*rng.uniform(-1.2, 1.2, 3)), medium=med, no_mat=True)
+    elif mode == 2:
+        med = pa.medium(rand_color(rng, 0.05, 0.5), rand_color(rng, 0.2, 1.0), float(rng.uniform(-0.3, 0.6)))
+        b.sphere(float(rng.uniform(0.5, 0.9)), pa.material("glass", index=1.33), S.translate(*rng.uniform(-1.2, 1.2, 3)), medium=med)
+    if seed % 4 == 3:
+        b.camera_medium = pa.medium((0.01, 0.01, 0.01), (0.04, 0.04, 0.05), 0.2)
+    sc = b.finish()
+    ang, elev = rng.uniform(0, 2 * np.pi), rng.uniform(0.1, 0.6)
+    eye = 7.0 * np.array([np.cos(ang) * np.cos(elev), np.sin(elev), np.sin(ang) * np.cos(elev)])
+    cam = pa.look_at_camera(eye, (0, -0.3, 0), (0, 1, 0), 42.0, W / H)
+    return sc, cam, eye
+
+
+SEEDS = list(range(12))
+
+
+@pytest.fixture(scope="module")
+def built(cuda):
+    cache = {}
+
+    def get(seed):
+        if seed not in cache:
+            sc, cam, eye = random_scene(seed)
+            o = orc.OracleScene(sc.flat, 0)
+            r = pa.Renderer(0)
+            r.upload(sc)
+            r.set_camera(cam)
+            cache[seed] = (sc, cam, eye, o, r)
+        return cache[seed]
+
+    yield get
+    for sc, cam, eye, o, r in cache.values():
+        r.close()
+        o.close()
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_hits(built, seed):
+    sc, cam, eye, o, r = built(seed)
+    n = 6000
+    rng = np.random.default_rng(seed)
+    tgt = rng.uniform(-2.5, 2.5, (3, n))
+    d = tgt - eye[:, None]
+    d /= np.linalg.norm(d, axis=0)
+    oc = np.repeat(eye[:, None], n, 1)
+    o2, d2 = common.random_rays(n, seed, -3.0, 3.0)
+    ro = np.concatenate([oc, o2], 1).astype(np.float32)
+    rd = np.concatenate([d, d2], 1).astype(np.float32)
+    tmax = np.full(2 * n, FMAX, np.float32)
+    tmax[n + n // 2:] = rng.uniform(0.2, 4.0, n - n // 2).astype(np.float32)  # bounded segments too
+    c = o.trace_closest(ro, rd, tmax)
+    g = common.gpu_trace_closest(r, ro, rd, tmax)
+    ok = c["order_dep"] == 0
+    assert ok.mean() > 0.98
+    assert np.array_equal(g["prim"][ok], c["prim"][ok]) and np.array_equal(g["face"][ok], c["face"][ok])
+    assert np.array_equal(g["prim"] >= 0, c["prim"] >= 0)
+    hit = c["prim"] >= 0
+    assert hit.mean() > 0.2
+    assert np.array_equal(g["t"][hit], c["t"][hit])
+    assert np.array_equal(o.trace_occluded(ro, rd, tmax) != 0, common.gpu_trace_occluded(r, ro, rd, tmax) != 0)
+
+
+@pytest.mark.parametrize("integ", list(common.INTEGRATORS))
+@pytest.mark.parametrize("seed", SEEDS)
+def test_image(built, seed, integ):
+    sc, cam, eye, o, r = built(seed)
+    r.film_init(W, H, SEED)
+    r.counters_reset()
+    r.render(SPP, common.INTEGRATORS[integ])
+    r.sync()
+    img = r.image()
+    o.counters_reset()
+    we, acc, osmp = o.render(cam, W, H, SEED, 0, SPP, common.INTEGRATORS[integ], 8)
+    ref = orc.image_of(we, acc).reshape(H, W, 3)
+    assert np.isfinite(img).all() and np.isfinite(ref).all()
+    assert ref.max() > 0
+    mean_rel, rmse_rel, off = common.image_stats(img, ref)
+    # At least 99 % of the pixels agree to 1e-3 relative.  The rest are paths on which a device-libm ulp flipped a discrete
+    # sampling decision; in these scenes (glass clouds and balls under small bright emitters, 8 spp) such a
+    # path can carry a firefly, so the RMSE of a 3 K-pixel image is one pixel's business and is not bounded here (measured
+    # 0.18-0.24 on three of the 48 cases with 0.2-0.65 % of pixels off, <= 0.02 on the others); the mean is held to 2 %.
+    assert off <= 0.01 and mean_rel <= 2e-2, (mean_rel, rmse_rel, off)
+    gc, oc = r.counters(), o.counters()
+    for k in ("total_paths", "shadow_rays", "mis_rays", "surface_hits", "medium_hits", "misses"):
+        assert abs(gc[k] - oc[k]) <= 0.005 * max(oc[k], 1) + 3, (k, gc[k], oc[k])
