@@ -150,6 +150,26 @@ def material(kind, **kw):
         _tex_float(tx[5], kw.get("clearcoat_gloss", 1.0))
         _tex_float(tx[6], kw.get("flatness", 0.0))
         m.n_textures = 7
+    elif kind == "subsurface":  # MakeSubsurfaceMaterial (scene.cpp): kr, kt, sigma_a, sigma_s (1/mm, times scale), roughness; vals scale, eta, g
+        m.type = capi.MAT_SUBSURFACE
+        _tex_spec(tx[0], kw.get("kr", (1, 1, 1)))
+        _tex_spec(tx[1], kw.get("kt", (1, 1, 1)))
+        _tex_spec(tx[2], kw.get("sigma_a", (0.0011, 0.0024, 0.014)))
+        _tex_spec(tx[3], kw.get("sigma_s", (2.55, 3.21, 3.77)))
+        _tex_float(tx[4], kw.get("uroughness", 0.0))
+        _tex_float(tx[5], kw.get("vroughness", 0.0))
+        m.vals[0], m.vals[1], m.vals[2] = float(kw.get("scale", 1.0)), float(kw.get("eta", 1.33)), float(kw.get("g", 0.0))
+        m.n_textures = 6
+    elif kind == "kdsubsurface":  # MakeKdSubsurfaceMaterial: kd, kt, kr, mean free path, roughness; vals eta, scale
+        m.type = capi.MAT_KDSUBSURFACE
+        _tex_spec(tx[0], kw.get("kd", (0.5, 0.5, 0.5)))
+        _tex_spec(tx[1], kw.get("kt", (1, 1, 1)))
+        _tex_spec(tx[2], kw.get("kr", (1, 1, 1)))
+        _tex_spec(tx[3], kw.get("mfp", (1, 1, 1)))
+        _tex_float(tx[4], kw.get("uroughness", 0.0))
+        _tex_float(tx[5], kw.get("vroughness", 0.0))
+        m.vals[0], m.vals[1] = float(kw.get("eta", 1.33)), float(kw.get("scale", 1.0))
+        m.n_textures = 6
     elif kind == "translucent":
         m.type = capi.MAT_TRANSLUCENT
         _tex_spec(tx[0], kw.get("kd", (0.25, 0.25, 0.25)))
