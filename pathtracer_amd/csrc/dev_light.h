@@ -165,6 +165,7 @@ PD void shape_sample_ref(const DScene &sc, int prim, const Ref &ref, const f2 &u
     case SH_SPHERE: sphere_sample_ref(pr, pr.o2w, pr.w2o, pr.p[0], pr.area, ref, u, it, pdf); return;
     case SH_CLOUD: { /* uses the RECEIVER's faceIndex, particlecloud.cpp:50 */
         const DCloud &c = sc.clouds[pr.geom];
+        if (c.n <= 0) { *pdf = 0; return; } /* an emitter without particles: nothing to sample (the reference would read past its array) */
         int part = ref.face;
         if (part < 0 || part >= c.n) part = 0;
         f3 ctr(c.pos[3 * part], c.pos[3 * part + 1], c.pos[3 * part + 2]);
@@ -198,6 +199,7 @@ PD void shape_sample_ref(const DScene &sc, int prim, const Ref &ref, const f2 &u
     }
     case SH_MESH: { /* mesh.cpp:387-422, uses the RECEIVER's faceIndex */
         const DMesh &m = sc.meshes[pr.geom];
+        if (m.n_tris <= 0) { *pdf = 0; return; } /* an emitter without triangles */
         int tri = ref.face;
         if (tri < 0 || tri >= m.n_tris) tri = 0;
         f3 p0, p1, p2;
@@ -250,6 +252,7 @@ PD float shape_pdf_ref(const DScene &sc, int prim, const Ref &ref, const f3 &wi)
     }
     case SH_MESH: { /* mesh.cpp:424-435 */
         const DMesh &m = sc.meshes[pr.geom];
+        if (m.n_tris <= 0) return 0;
         int tri = ref.face;
         if (tri < 0 || tri >= m.n_tris) tri = 0;
         f3 ro = spawn_origin(ref, wi);

@@ -362,6 +362,8 @@ int ptr_flatten(const PtrFlatScene *fs, HostScene *hs, std::string *err) {
     if (!fs || !hs) return fail(err, PTR_ERR_INVALID, "null scene");
     if (fs->n_primitives < 0 || fs->n_meshes < 0 || fs->n_clouds < 0 || fs->n_images < 0)
         return fail(err, PTR_ERR_INVALID, "negative count in PtrFlatScene");
+    if ((fs->n_primitives > 0 && !fs->primitives) || (fs->n_meshes > 0 && !fs->meshes) || (fs->n_clouds > 0 && !fs->clouds) || (fs->n_images > 0 && !fs->images))
+        return fail(err, PTR_ERR_INVALID, "null array with a non-zero count in PtrFlatScene");
     *hs = HostScene();
 
     for (int i = 0; i < fs->n_images; i++) {

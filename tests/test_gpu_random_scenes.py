@@ -118,6 +118,20 @@ def random_scene(seed):
         b.sphere(float(rng.uniform(0.15, 0.4)), pa.material("emissive", L=rand_color(rng, 5, 20)), S.translate(*rng.uniform(-2, 2, 3)))
     if extra == 2:
         b.disk(0.0, float(rng.uniform(0.3, 0.7)), 0.0, 360.0, pa.material("emissive", L=rand_color(rng, 5, 20)), rand_pose(rng))
+    if seed >= 44:  # emitters of the other shape types: a mesh, a particle cloud, an SDF box, a rectangle among the objects
+        for _ in range(int(rng.integers(1, 3))):
+            kind = rng.choice(["mesh", "cloud", "box", "rectangle"])
+            em = pa.material("emissive", L=rand_color(rng, 2, 9))
+            if kind == "mesh":
+                v, t = bumpy_grid(rng, int(rng.integers(1, 5)))
+                b.mesh(0.5 * v, t, em, rand_pose(rng))
+            elif kind == "cloud":
+                n = int(rng.integers(1, 30))
+                b.cloud((rng.normal(0, 0.4, (n, 3)) + rng.uniform(-1.5, 1.5, 3)).astype(np.float32), float(rng.uniform(0.05, 0.15)), em)
+            elif kind == "box":
+                b.box(0.3, 0.2, 0.4, em, rand_pose(rng))
+            else:
+                b.rectangle(0.8, 0.5, em, rand_pose(rng))
     # media: seed % 3 == 1: a medium inside a boundary without material; == 2: inside a glass ball; every fourth scene: fog at the camera
     mode = seed % 3
     if mode == 1:
@@ -138,7 +152,7 @@ def random_scene(seed):
     return sc, cam, eye
 
 
-SEEDS = list(range(44))
+SEEDS = list(range(54))
 
 
 @pytest.fixture(scope="module")
