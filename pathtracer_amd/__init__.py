@@ -8,4 +8,4 @@ from . import assets, capi  # noqa: F401
 from .capi import (LI_DIRECT, LI_PATH, LI_PATHSAMPLED, LI_VOLPATH, TONEMAP_EXPONENTIAL, TONEMAP_NAUGHTYDOG,  # noqa: F401
                    TONEMAP_REINHARD, PtrError)  # noqa: F401
 from .render import Renderer, set_bvh_build_mode  # noqa: F401
-from .scene import BuiltScene, FlatSceneBuilder, look_at_camera, material, medium  # noqa: F401
+from .scene import BuiltScene, FlatSceneBuilder, ImageTexture, look_at_camera, material, medium  # noqa: F401

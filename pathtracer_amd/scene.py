@@ -80,7 +80,18 @@ def rotate_x(deg):
     return np.array([[1, 0, 0, 0], [0, c, -s, 0], [0, s, c, 0], [0, 0, 0, 1]])
 
 
+class ImageTexture:
+    """A spectrum slot that reads image `index` of the scene (FlatSceneBuilder.image) at the hit's uv."""
+
+    def __init__(self, index):
+        self.index = int(index)
+
+
 def _tex_spec(t, rgb):
+    if isinstance(rgb, ImageTexture):
+        t.type = 2
+        t.image = rgb.index
+        return
     t.type = 0
     t.spec[:] = [float(v) for v in rgb]
 
@@ -260,6 +271,16 @@ class FlatSceneBuilder:
         self._keep += [v, idx]
         self.meshes.append(m)
         return self._prim(capi.SHAPE_MESH, [], mat, None, geom=len(self.meshes) - 1, **kw)
+
+    def image(self, rgb):
+        """float32 [h, w, 3] texels, rows top-down (what LoadTextureImageData returns) -> ImageTexture for a spectrum slot"""
+        a = np.ascontiguousarray(rgb, dtype=np.float32)
+        im = capi.PtrImage()
+        im.height, im.width = a.shape[0], a.shape[1]
+        im.rgb = a.ctypes.data_as(capi.fptr)
+        self._keep.append(a)
+        self.images.append(im)
+        return ImageTexture(len(self.images) - 1)
 
     def cloud(self, positions, radius, mat, **kw):
         p = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 3)

@@ -80,8 +80,24 @@ def bumpy_grid(rng, n):
     return v, tri
 
 
-def add_shape(b, rng, mat, **kw):
+def textured_material(b, rng):
+    """image textures in the colour slots: the uv parametrisation of every shape type decides what is seen"""
+    h, w = int(rng.integers(2, 40)), int(rng.integers(2, 40))
+    tex = b.image(rng.uniform(0.05, 0.95, (h, w, 3)).astype(np.float32))
+    kind = rng.choice(["matte", "plastic", "uber", "mirror"])
+    if kind == "matte":
+        return pa.material("matte", kd=tex)
+    if kind == "plastic":
+        return pa.material("plastic", kd=tex, ks=rand_color(rng, 0.05, 0.3), roughness=float(rng.uniform(0.05, 0.4)))
+    if kind == "uber":
+        return pa.material("uber", kd=tex, ks=tex, kr=rand_color(rng, 0, 0.2), kt=rand_color(rng, 0, 0.2), opacity=tex)
+    return pa.material("mirror", kr=tex)
+
+
+def add_shape(b, rng, mat, textured=False, **kw):
     kind = rng.choice(["sphere", "rectangle", "disk", "box", "sphere_procedural", "mesh", "cloud"])
+    if textured and rng.uniform() < 0.7:
+        mat = textured_material(b, rng)
     pose = rand_pose(rng)
     if kind in ("sphere", "rectangle", "disk") and rng.uniform() < 0.25:
         kw = dict(kw, reverse=True)  # ReverseOrientation: the normal flips, and with it the medium sides
@@ -97,6 +113,13 @@ def add_shape(b, rng, mat, **kw):
         return b.sphere_procedural(float(rng.uniform(0.3, 0.8)), mat, pose, **kw)
     if kind == "mesh":
         v, t = bumpy_grid(rng, int(rng.integers(3, 14)))
+        if textured:  # per-vertex uvs from the grid position; every other mesh shares corner indices, the others get their own uv list order
+            uv = (v[:, :2] * 0.5 + 0.5).astype(np.float32)
+            if rng.uniform() < 0.5:
+                perm = rng.permutation(len(uv))
+                inv = np.argsort(perm)
+                return b.mesh(v, t, mat, pose, uvs=uv[perm], uv_triangles=inv[t], **kw)
+            return b.mesh(v, t, mat, pose, uvs=uv, **kw)
         return b.mesh(v, t, mat, pose, **kw)
     n = int(rng.integers(20, 400))
     pos = (rng.normal(0, 0.5, (n, 3)) + rng.uniform(-1.5, 1.5, 3)).astype(np.float32)
@@ -109,7 +132,7 @@ def random_scene(seed):
     # a floor, so that most paths have somewhere to go
     b.rectangle(9.0, 9.0, pa.material("matte", kd=rand_color(rng, 0.4, 0.8)), S.translate(0, -2.2, 0) @ S.rotate_x(90))
     for _ in range(int(rng.integers(3, 8))):
-        add_shape(b, rng, rand_material(rng, sss=seed >= 32))  # seeds 32..: BSSRDF materials in the draw (the SSS kernels shade such scenes)
+        add_shape(b, rng, rand_material(rng, sss=32 <= seed < 54), textured=seed >= 54)  # seeds 32..: BSSRDF materials in the draw (the SSS kernels shade such scenes)
     # emitters: a panel overhead always, sometimes a ball or a disk among the objects
     px, pz = rng.uniform(-1, 1, 2)
     b.rectangle(2.0, 2.0, pa.material("emissive", L=rand_color(rng, 4, 12)), S.translate(px, 3.2, pz) @ S.rotate_x(90))
@@ -152,7 +175,7 @@ def random_scene(seed):
     return sc, cam, eye
 
 
-SEEDS = list(range(54))
+SEEDS = list(range(64))
 
 
 @pytest.fixture(scope="module")
