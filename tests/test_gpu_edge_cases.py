@@ -172,3 +172,37 @@ def test_extents_and_origins(cuda):
     d /= np.linalg.norm(d, axis=0, keepdims=True)
     for tmax in (FMAX, 1.0, 1e-3, 0.0):
         compare(sc, o, d, np.full(2 * n, tmax, np.float32), "host")
+
+
+def test_non_finite_and_null_rays(cuda):
+    """NaN / infinite / zero-length components in origins, directions and extents: every ray ends (the persistent tracer
+    drains), and since the comparisons involved are IEEE comparisons on both sides the answers equal the oracle's"""
+    sc = common.build("zoo", 64, 48)  # analytic shapes, SDF shapes, a mesh
+    o_sc = common.oracle_of(sc)
+    r = pa.Renderer(0)
+    r.upload(sc)
+    n = 4096
+    o, d = common.random_rays(n, 9, -3.0, 3.0)
+    tm = np.full(n, FMAX, np.float32)
+    rng = np.random.default_rng(4)
+    bad = [np.nan, np.inf, -np.inf, 0.0, -0.0, FMAX, -FMAX, 1e-45]
+    for i in range(0, n, 2):  # every other ray gets one to three bad words
+        for _ in range(int(rng.integers(1, 4))):
+            which, c, v = int(rng.integers(0, 3)), int(rng.integers(0, 3)), np.float32(rng.choice(bad))
+            if which == 0:
+                o[c, i] = v
+            elif which == 1:
+                d[c, i] = v
+            else:
+                tm[i] = v
+    d[:, 10] = 0  # a null direction
+    c = o_sc.trace_closest(o, d, tm)
+    g = common.gpu_trace_closest(r, o, d, tm)
+    ok = c["order_dep"] == 0
+    assert np.array_equal(g["prim"][ok], c["prim"][ok])
+    hit = (c["prim"] >= 0) & ok
+    assert np.array_equal(g["t"][hit], c["t"][hit])
+    assert np.array_equal(o_sc.trace_occluded(o, d, tm) != 0, common.gpu_trace_occluded(r, o, d, tm) != 0)
+    r.close()
+    o_sc.close()
+    sc.close()
