@@ -288,6 +288,10 @@ typedef struct PtrBvhBuildInfo {
 } PtrBvhBuildInfo;
 int ptr_bvh_build_info(PtrContext *ctx, PtrBvhBuildInfo *out);
 int ptr_scene_built_info(const PtrBuiltScene *built, PtrBvhBuildInfo *out); /* the same of a scene not uploaded yet */
+/* 64-bit FNV-1a over the built scene's traversal tables (4-wide nodes, leaf items, top-level nodes and order): equal scenes
+ * built by equal builders hash equal - the host SAH build is deterministic whatever its thread count (PTR_BUILD_THREADS).
+ * No counterpart in the reference; for determinism tests and caches of built scenes. */
+int ptr_scene_built_hash(const PtrBuiltScene *built, uint64_t *out);
 /* Replaces Camera::Config's writes into the managed Camera (camera.cpp:145-197). */
 int ptr_camera_set(PtrContext *ctx, const PtrCamera *cam);
 

@@ -117,6 +117,7 @@ HIP_SIGNATURES = {
     "ptr_bvh_build_info": (C.c_int, [CTX, C.POINTER(PtrBvhBuildInfo)]),
     "ptr_scene_built_info": (C.c_int, [C.c_void_p, C.POINTER(PtrBvhBuildInfo)]),
     "ptr_scene_build": (C.c_int, [C.POINTER(PtrFlatScene), C.POINTER(C.c_void_p)]),
+    "ptr_scene_built_hash": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "ptr_scene_upload_built": (C.c_int, [CTX, C.c_void_p]),
     "ptr_scene_built_free": (C.c_int, [C.c_void_p]),
     "ptr_camera_set": (C.c_int, [CTX, C.POINTER(PtrCamera)]),

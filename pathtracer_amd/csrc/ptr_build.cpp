@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 namespace {
 
@@ -93,16 +94,25 @@ struct Builder {
     const std::vector<Box> &boxes;
     std::vector<uint32_t> idx;
     std::vector<float> cen; /* 3 per item */
-    std::vector<Node64> nodes;
-    std::vector<uint32_t> order;
+    /* what a (sub)tree is built into: node refs and leaf item positions are relative to these two vectors, so that subtrees
+     * built by different threads can be spliced behind one another and come out numbered as the serial build numbers them */
+    struct Out {
+        std::vector<Node64> nodes;
+        std::vector<uint32_t> order;
+        int max_depth = 0;
+    };
+    Out top;
+    std::vector<Node64> &nodes = top.nodes;
+    std::vector<uint32_t> &order = top.order;
     int max_depth = 0;
-    int32_t node_base = 0;
     uint32_t item_base = 0;
     static const int NB = 32;
     float c_trav = 1.0f;  /* SAH: cost of one binary split relative to one item test */
     size_t always_leaf = 2; /* ranges of at most this many items are leaves without asking the SAH */
+    int par_levels = 4;     /* the two halves of a split are built by two threads down to this depth (PTR_BUILD_THREADS=1: serial) */
+    static const size_t PAR_MIN = 1 << 14;
 
-    Builder(const std::vector<Box> &b, size_t nbase, size_t ibase) : boxes(b), node_base((int32_t)nbase), item_base((uint32_t)ibase) {
+    Builder(const std::vector<Box> &b, size_t /*nbase*/, size_t ibase) : boxes(b), item_base((uint32_t)ibase) {
         idx.resize(b.size());
         cen.resize(3 * b.size());
         for (size_t i = 0; i < b.size(); i++) {
@@ -111,26 +121,85 @@ struct Builder {
         }
         if (const char *e = getenv("PTR_SAH_CT")) c_trav = (float)atof(e);
         if (const char *e = getenv("PTR_SAH_ALWAYS_LEAF")) always_leaf = (size_t)atoi(e);
+        if (const char *e = getenv("PTR_BUILD_THREADS")) {
+            int t = atoi(e);
+            par_levels = 0;
+            while ((1 << (par_levels + 1)) <= t) par_levels++;
+        }
     }
-    int32_t make_leaf(size_t lo, size_t hi) {
-        uint32_t first = item_base + (uint32_t)order.size(), n = (uint32_t)(hi - lo);
-        for (size_t i = lo; i < hi; i++) order.push_back(idx[i]);
-        uint32_t packed = first | ((n - 1) << 27);
-        return -(int32_t)packed - 1;
+    static int32_t leaf_ref(uint32_t first, uint32_t n) { return -(int32_t)(first | ((n - 1) << 27)) - 1; }
+    static int32_t make_leaf(const std::vector<uint32_t> &idx, size_t lo, size_t hi, Out &out) {
+        uint32_t first = (uint32_t)out.order.size(), n = (uint32_t)(hi - lo);
+        for (size_t i = lo; i < hi; i++) out.order.push_back(idx[i]);
+        return leaf_ref(first, n);
     }
-    /* returns the child ref for items [lo, hi) and their box */
+    /* a ref of a subtree that is being appended behind node_off nodes and item_off items */
+    static int32_t moved(int32_t ref, int32_t node_off, uint32_t item_off) {
+        if (ref >= 0) return ref + node_off;
+        const uint32_t packed = (uint32_t)(-(ref + 1));
+        return leaf_ref((packed & 0x07FFFFFFu) + item_off, (packed >> 27) + 1);
+    }
+    static int32_t splice(Out &into, const Out &sub, int32_t sub_root) {
+        const int32_t node_off = (int32_t)into.nodes.size();
+        const uint32_t item_off = (uint32_t)into.order.size();
+        for (Node64 nd : sub.nodes) {
+            nd.left = moved(nd.left, node_off, item_off);
+            nd.right = moved(nd.right, node_off, item_off);
+            into.nodes.push_back(nd);
+        }
+        into.order.insert(into.order.end(), sub.order.begin(), sub.order.end());
+        if (sub.max_depth > into.max_depth) into.max_depth = sub.max_depth;
+        return moved(sub_root, node_off, item_off);
+    }
+    /* the whole tree: refs of inner nodes index `nodes`, leaf refs carry item_base */
     int32_t build(size_t lo, size_t hi, Box *outBox, int depth) {
+        int32_t root = build_range(lo, hi, outBox, depth, top, par_levels);
+        max_depth = top.max_depth;
+        for (Node64 &nd : top.nodes) {
+            nd.left = moved(nd.left, 0, item_base);
+            nd.right = moved(nd.right, 0, item_base);
+        }
+        return moved(root, 0, item_base);
+    }
+    /* fn(chunk, begin, end) over [lo, hi) cut into `chunks` pieces, one thread each (the caller's among them).  What the
+     * pieces compute is merged with min / max / integer sums only, so the result does not depend on the cut. */
+    template <class F>
+    static void for_chunks(size_t lo, size_t hi, int chunks, const F &fn) {
+        if (chunks <= 1) { fn(0, lo, hi); return; }
+        std::vector<std::thread> th;
+        const size_t n = hi - lo;
+        for (int c = 1; c < chunks; c++) th.emplace_back([&, c] { fn(c, lo + n * c / chunks, lo + n * (c + 1) / chunks); });
+        fn(0, lo, lo + n / chunks);
+        for (std::thread &t : th) t.join();
+    }
+    static const int MAX_CHUNKS = 16;
+    /* returns the child ref for items [lo, hi) and their box */
+    int32_t build_range(size_t lo, size_t hi, Box *outBox, int depth, Out &out, int par) {
         size_t n = hi - lo;
+        /* the sweeps over a large range near the root, where there are fewer subtrees than threads, are cut into pieces */
+        int chunks = (par > 0 && n >= 8 * PAR_MIN) ? (1 << par) : 1;
+        if (chunks > MAX_CHUNKS) chunks = MAX_CHUNKS;
         Box bb, cb;
         bb.reset();
         cb.reset();
-        for (size_t i = lo; i < hi; i++) {
-            bb.grow(boxes[idx[i]]);
-            cb.grow(&cen[3 * idx[i]]);
+        {
+            Box pbb[MAX_CHUNKS], pcb[MAX_CHUNKS];
+            for_chunks(lo, hi, chunks, [&](int c, size_t b0, size_t b1) {
+                Box x, y;
+                x.reset();
+                y.reset();
+                for (size_t i = b0; i < b1; i++) {
+                    x.grow(boxes[idx[i]]);
+                    y.grow(&cen[3 * idx[i]]);
+                }
+                pbb[c] = x;
+                pcb[c] = y;
+            });
+            for (int c = 0; c < chunks; c++) { bb.grow(pbb[c]); cb.grow(pcb[c]); }
         }
         *outBox = bb;
-        if (depth > max_depth) max_depth = depth;
-        if (n <= always_leaf) return make_leaf(lo, hi);
+        if (depth > out.max_depth) out.max_depth = depth;
+        if (n <= always_leaf) return make_leaf(idx, lo, hi, out);
 
         size_t mid = 0;
         bool have_split = false;
@@ -144,12 +213,31 @@ struct Builder {
                 uint32_t bin_n[NB];
                 for (int b = 0; b < NB; b++) { bin_box[b].reset(); bin_n[b] = 0; }
                 float scale = NB / ext;
-                for (size_t i = lo; i < hi; i++) {
-                    int b = (int)((cen[3 * idx[i] + a] - cb.mn[a]) * scale);
-                    if (b < 0) b = 0;
-                    if (b > NB - 1) b = NB - 1;
-                    bin_box[b].grow(boxes[idx[i]]);
-                    bin_n[b]++;
+                if (chunks == 1) {
+                    for (size_t i = lo; i < hi; i++) {
+                        int b = (int)((cen[3 * idx[i] + a] - cb.mn[a]) * scale);
+                        if (b < 0) b = 0;
+                        if (b > NB - 1) b = NB - 1;
+                        bin_box[b].grow(boxes[idx[i]]);
+                        bin_n[b]++;
+                    }
+                } else {
+                    std::vector<Box> pbox((size_t)chunks * NB);
+                    std::vector<uint32_t> pn((size_t)chunks * NB, 0u);
+                    for (Box &x : pbox) x.reset();
+                    for_chunks(lo, hi, chunks, [&](int c, size_t b0, size_t b1) {
+                        Box *mybox = &pbox[(size_t)c * NB];
+                        uint32_t *myn = &pn[(size_t)c * NB];
+                        for (size_t i = b0; i < b1; i++) {
+                            int b = (int)((cen[3 * idx[i] + a] - cb.mn[a]) * scale);
+                            if (b < 0) b = 0;
+                            if (b > NB - 1) b = NB - 1;
+                            mybox[b].grow(boxes[idx[i]]);
+                            myn[b]++;
+                        }
+                    });
+                    for (int c = 0; c < chunks; c++)
+                        for (int b = 0; b < NB; b++) { bin_box[b].grow(pbox[(size_t)c * NB + b]); bin_n[b] += pn[(size_t)c * NB + b]; }
                 }
                 float right_area[NB];
                 uint32_t right_n[NB];
@@ -175,7 +263,7 @@ struct Builder {
             if (best_axis >= 0) {
                 float parent = bb.half_area();
                 float split_cost = c_trav + (parent > 0 ? best_cost / parent : (float)n);
-                if (n <= BVH_MAX_LEAF && (float)n <= split_cost) return make_leaf(lo, hi);
+                if (n <= BVH_MAX_LEAF && (float)n <= split_cost) return make_leaf(idx, lo, hi, out);
                 float ext = cb.mx[best_axis] - cb.mn[best_axis];
                 float scale = NB / ext;
                 float cmin = cb.mn[best_axis];
@@ -190,7 +278,7 @@ struct Builder {
             }
         }
         if (!have_split) {
-            if (n <= BVH_MAX_LEAF) return make_leaf(lo, hi);
+            if (n <= BVH_MAX_LEAF) return make_leaf(idx, lo, hi, out);
             /* coincident centroids or depth guard: split the index range in half on the widest axis */
             int a = 0;
             float e0 = cb.mx[0] - cb.mn[0], e1 = cb.mx[1] - cb.mn[1], e2 = cb.mx[2] - cb.mn[2];
@@ -200,17 +288,29 @@ struct Builder {
             std::nth_element(idx.begin() + lo, idx.begin() + mid, idx.begin() + hi,
                              [&](uint32_t x, uint32_t y) { return cen[3 * x + a] < cen[3 * y + a]; });
         }
-        int32_t me = (int32_t)nodes.size();
-        nodes.emplace_back();
-        const int32_t me_global = node_base + me;
+        int32_t me = (int32_t)out.nodes.size();
+        out.nodes.emplace_back();
         Box lb, rb;
-        int32_t l = build(lo, mid, &lb, depth + 1);
-        int32_t r = build(mid, hi, &rb, depth + 1);
-        Node64 &nd = nodes[me];
+        int32_t l, r;
+        if (par > 0 && n >= PAR_MIN) {
+            /* the halves are disjoint ranges of idx: the left one in another thread, each into its own vectors, appended in the
+             * serial build's order (this node, the left subtree, the right subtree) */
+            Out lo_out, hi_out;
+            int32_t l_rel = 0;
+            std::thread th([&] { l_rel = build_range(lo, mid, &lb, depth + 1, lo_out, par - 1); });
+            const int32_t r_rel = build_range(mid, hi, &rb, depth + 1, hi_out, par - 1);
+            th.join();
+            l = splice(out, lo_out, l_rel);
+            r = splice(out, hi_out, r_rel);
+        } else {
+            l = build_range(lo, mid, &lb, depth + 1, out, 0);
+            r = build_range(mid, hi, &rb, depth + 1, out, 0);
+        }
+        Node64 &nd = out.nodes[me];
         for (int i = 0; i < 3; i++) { nd.lmin[i] = lb.mn[i]; nd.lmax[i] = lb.mx[i]; nd.rmin[i] = rb.mn[i]; nd.rmax[i] = rb.mx[i]; }
         nd.left = l;
         nd.right = r;
-        return me_global;
+        return me;
     }
 };
 
@@ -443,8 +543,11 @@ int ptr_flatten(const PtrFlatScene *fs, HostScene *hs, std::string *err) {
         b.nodes.reserve(boxes.size());
         b.order.reserve(boxes.size());
         const int32_t root2 = b.build(0, boxes.size(), bound, 0);
+        const auto t_mid = std::chrono::steady_clock::now();
         Collapser c(b.nodes, hs->nodes);
         *root = c.emit(root2, 0);
+        if (getenv("PTR_BUILD_VERBOSE")) fprintf(stderr, "sah build %zu items: binary tree %.1f ms, collapse %.1f ms\n", boxes.size(),
+            std::chrono::duration<double, std::milli>(t_mid - t_begin).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_mid).count());
         /* per lane: up to three pushed siblings per level of this tree, on top of the top-level walk's entries
          * (the persistent tracer keeps both in one stack; the reference's top tree is at most 20 deep) */
         if (3 * (c.max_depth + 1) + 24 > BVH_STACK) return fail(err, PTR_ERR_LIMIT, "BVH deeper than the traversal stack");

@@ -933,6 +933,21 @@ int ptr_scene_built_info(const PtrBuiltScene *built, PtrBvhBuildInfo *out) {
     *out = built_info(built->hs);
     return PTR_OK;
 }
+int ptr_scene_built_hash(const PtrBuiltScene *built, uint64_t *out) {
+    if (!built || !out) return set_err(PTR_ERR_INVALID, "null argument");
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&h](const void *p, size_t n) {
+        const unsigned char *b = static_cast<const unsigned char *>(p);
+        for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; }
+    };
+    const HostScene &hs = built->hs;
+    if (!hs.nodes.empty()) mix(hs.nodes.data(), hs.nodes.size() * sizeof(hs.nodes[0]));
+    if (!hs.items.empty()) mix(hs.items.data(), hs.items.size() * sizeof(hs.items[0]));
+    if (!hs.top.empty()) mix(hs.top.data(), hs.top.size() * sizeof(hs.top[0]));
+    if (!hs.order.empty()) mix(hs.order.data(), hs.order.size() * sizeof(hs.order[0]));
+    *out = h;
+    return PTR_OK;
+}
 int ptr_scene_built_free(PtrBuiltScene *built) {
     delete built;
     return PTR_OK;

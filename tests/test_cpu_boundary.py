@@ -182,3 +182,36 @@ def test_host_sah_tree_quality():
     sc.close()
     assert o.builder == 0 and 3 <= o.depth <= 23 and o.build_ms > 0
     assert o.sah_boxes < 65 and o.sah_items < 28 and 1.5 < o.sah_items / o.sah_leaves <= 4
+
+
+def test_host_sah_build_is_the_same_tree_for_any_thread_count():
+    """The halves of a split are built by different threads and the large sweeps near the root are cut into pieces
+    (ptr_build.cpp); subtrees are spliced in the serial build's order and the pieces merged with min / max / integer sums,
+    so the tables are the serial build's, byte for byte."""
+    import ctypes as C
+    import os
+
+    import pathtracer_amd as pa
+    from pathtracer_amd import capi
+
+    sc = pa.BuiltScene("knot", 64, 36, 300, 0)  # 180,000 triangles: above both thresholds
+    hashes = {}
+    old = os.environ.get("PTR_BUILD_THREADS")
+    try:
+        for threads in ("1", "2", "3", "8", "16", None):
+            if threads is None:
+                os.environ.pop("PTR_BUILD_THREADS", None)
+            else:
+                os.environ["PTR_BUILD_THREADS"] = threads
+            b, h = C.c_void_p(), C.c_uint64()
+            capi.check(capi.hip().ptr_scene_build(sc.flat, C.byref(b)))
+            capi.check(capi.hip().ptr_scene_built_hash(b, C.byref(h)))
+            capi.check(capi.hip().ptr_scene_built_free(b))
+            hashes[threads] = h.value
+    finally:
+        if old is None:
+            os.environ.pop("PTR_BUILD_THREADS", None)
+        else:
+            os.environ["PTR_BUILD_THREADS"] = old
+    sc.close()
+    assert len(set(hashes.values())) == 1, hashes
