@@ -206,3 +206,39 @@ def test_non_finite_and_null_rays(cuda):
     r.close()
     o_sc.close()
     sc.close()
+
+
+@pytest.mark.parametrize("size", [(1, 1), (3, 2), (7, 5)])
+def test_tiny_films_and_many_samples(cuda, size):
+    """films of a few pixels with sample counts that straddle the pass size (64 samples of every pixel) and the six lanes:
+    the sample counts are exact, a render split over calls is the single render bit for bit, the picture is the oracle's"""
+    w, h = size
+    sc = common.build("cornell", w, h)
+    o_sc = common.oracle_of(sc)
+    with pa.Renderer(0) as r:
+        r.upload(sc)
+        r.set_camera(sc.camera)
+        for ns in (1, 63, 64, 65, 129, 777):
+            r.film_init(w, h, 5)
+            r.render(ns, pa.LI_PATHSAMPLED)
+            we, acc, smp = r.film()
+            assert np.all(smp == ns)
+            one = we.copy()
+            r.film_init(w, h, 5)
+            left = ns
+            for part in (1, 64, 2, 300, 10 ** 6):
+                k = min(part, left)
+                r.render(k, pa.LI_PATHSAMPLED)
+                left -= k
+                if left == 0:
+                    break
+            assert np.array_equal(r.film()[0], one)
+        img = r.image()
+        we, acc, osmp = o_sc.render(sc.camera, w, h, 5, 0, 777, pa.LI_PATHSAMPLED, 8)
+        ref = orc.image_of(we, acc).reshape(h, w, 3)
+        assert np.allclose(img, ref, rtol=2e-2, atol=1e-3), (img, ref)
+        r.film_init(w, h, 5)
+        r.render(0, pa.LI_PATH)  # nothing to do is not an error
+        assert np.all(r.film()[2] == 0)
+    o_sc.close()
+    sc.close()
