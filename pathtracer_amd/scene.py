@@ -194,6 +194,19 @@ def material(kind, **kw):
     return m
 
 
+class _EnvTables:
+    """keeps the tables of ptr_envmap_build alive as long as the scene that points at them"""
+
+    def __init__(self, handle):
+        self.handle = handle
+
+    def __del__(self):
+        try:
+            capi.hip().ptr_envmap_free(self.handle)
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+
 class FlatSceneBuilder:
     def __init__(self):
         self.prims, self.meshes, self.clouds, self.images = [], [], [], []
@@ -291,6 +304,19 @@ class FlatSceneBuilder:
         self.clouds.append(c)
         return self._prim(capi.SHAPE_PARTICLECLOUD, [], mat, None, geom=len(self.clouds) - 1, **kw)
 
+    def envmap(self, rgb, scale=(1, 1, 1), to_world=None, device=-1):
+        """InsertLightMap for this scene: the light-map tables of float32 [h, w, 3] texels (rows top-down) built on the GPU
+        (ptr_envmap_build: the floats the host pipeline gives), attached when the scene is finished."""
+        a = np.ascontiguousarray(rgb, dtype=np.float32)
+        sc3 = (C.c_float * 3)(*[float(v) for v in scale])
+        h = C.c_void_p()
+        capi.check(capi.hip().ptr_envmap_build(int(device), a.ctypes.data_as(capi.fptr), a.shape[1], a.shape[0], sc3, C.byref(h)))
+        view = capi.PtrEnvMap()
+        capi.check(capi.hip().ptr_envmap_view(h, C.byref(view), None))
+        view.light_to_world = transform(to_world)
+        self._env = (h, view)
+        self._keep.append(_EnvTables(h))
+
     def finish(self):
         fs = capi.PtrFlatScene()
         fs.n_primitives, fs.n_meshes, fs.n_clouds, fs.n_images = len(self.prims), len(self.meshes), len(self.clouds), len(self.images)
@@ -301,6 +327,9 @@ class FlatSceneBuilder:
         fs.primitives, fs.meshes, fs.clouds, fs.images = pa, ma, ca, ia
         if self.camera_medium is not None:
             fs.camera_medium = self.camera_medium
+        if getattr(self, "_env", None) is not None:
+            fs.has_envmap = 1
+            fs.envmap = self._env[1]
         self._keep += [pa, ma, ca, ia]
         return PyScene(fs, self._keep)
 

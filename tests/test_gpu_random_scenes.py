@@ -132,7 +132,7 @@ def random_scene(seed):
     # a floor, so that most paths have somewhere to go
     b.rectangle(9.0, 9.0, pa.material("matte", kd=rand_color(rng, 0.4, 0.8)), S.translate(0, -2.2, 0) @ S.rotate_x(90))
     for _ in range(int(rng.integers(3, 8))):
-        add_shape(b, rng, rand_material(rng, sss=32 <= seed < 54), textured=seed >= 54)  # seeds 32..: BSSRDF materials in the draw (the SSS kernels shade such scenes)
+        add_shape(b, rng, rand_material(rng, sss=32 <= seed < 54 or seed >= 68), textured=54 <= seed < 68)  # seeds 32..: BSSRDF materials in the draw (the SSS kernels shade such scenes)
     # emitters: a panel overhead always, sometimes a ball or a disk among the objects
     px, pz = rng.uniform(-1, 1, 2)
     b.rectangle(2.0, 2.0, pa.material("emissive", L=rand_color(rng, 4, 12)), S.translate(px, 3.2, pz) @ S.rotate_x(90))
@@ -155,6 +155,11 @@ def random_scene(seed):
                 b.box(0.3, 0.2, 0.4, em, rand_pose(rng))
             else:
                 b.rectangle(0.8, 0.5, em, rand_pose(rng))
+    if seed >= 64:  # a sky: a random light map (odd sizes: the Lanczos resample to powers of two runs), rotated, next to the emitters
+        hh, ww = int(rng.integers(5, 40)), int(rng.integers(8, 70))
+        sky = rng.uniform(0.0, 0.6, (hh, ww, 3)).astype(np.float32)
+        sky[int(rng.integers(0, hh)), int(rng.integers(0, ww))] = rng.uniform(20, 60, 3)  # a sun
+        b.envmap(sky, scale=rand_color(rng, 0.5, 1.5), to_world=S.rotate_y(float(rng.uniform(0, 360))) @ S.rotate_x(float(rng.uniform(-90, 90))))
     # media: seed % 3 == 1: a medium inside a boundary without material; == 2: inside a glass ball; every fourth scene: fog at the camera
     mode = seed % 3
     if mode == 1:
@@ -175,7 +180,7 @@ def random_scene(seed):
     return sc, cam, eye
 
 
-SEEDS = list(range(64))
+SEEDS = list(range(72))
 
 
 @pytest.fixture(scope="module")
