@@ -131,7 +131,24 @@ def random_scene(seed):
     b = pa.FlatSceneBuilder()
     # a floor, so that most paths have somewhere to go
     b.rectangle(9.0, 9.0, pa.material("matte", kd=rand_color(rng, 0.4, 0.8)), S.translate(0, -2.2, 0) @ S.rotate_x(90))
-    for _ in range(int(rng.integers(3, 8))):
+    crowd = seed >= 72  # seeds 72..: 40-150 small objects (the top-level tree outgrows its LDS copy) and dozens of emitters
+    if crowd:
+        for _ in range(int(rng.integers(40, 150))):
+            mat = rand_material(rng) if rng.uniform() > 0.25 else pa.material("emissive", L=rand_color(rng, 0.5, 4))
+            pose = S.translate(*rng.uniform(-2.5, 2.5, 3)) @ S.rotate_y(float(rng.uniform(0, 360))) @ S.rotate_x(float(rng.uniform(0, 360)))
+            k = int(rng.integers(0, 5))
+            if k == 0:
+                b.sphere(float(rng.uniform(0.05, 0.3)), mat, pose)
+            elif k == 1:
+                b.rectangle(float(rng.uniform(0.1, 0.6)), float(rng.uniform(0.1, 0.6)), mat, pose)
+            elif k == 2:
+                b.disk(0.0, float(rng.uniform(0.1, 0.3)), 0.0, 360.0, mat, pose)
+            elif k == 3:
+                b.box(float(rng.uniform(0.05, 0.25)), float(rng.uniform(0.05, 0.25)), float(rng.uniform(0.05, 0.25)), mat, pose)
+            else:
+                v, t = bumpy_grid(rng, int(rng.integers(1, 4)))
+                b.mesh(0.3 * v, t, mat, pose)
+    for _ in range(0 if crowd else int(rng.integers(3, 8))):
         add_shape(b, rng, rand_material(rng, sss=32 <= seed < 54 or seed >= 68), textured=54 <= seed < 68)  # seeds 32..: BSSRDF materials in the draw (the SSS kernels shade such scenes)
     # emitters: a panel overhead always, sometimes a ball or a disk among the objects
     px, pz = rng.uniform(-1, 1, 2)
@@ -155,7 +172,7 @@ def random_scene(seed):
                 b.box(0.3, 0.2, 0.4, em, rand_pose(rng))
             else:
                 b.rectangle(0.8, 0.5, em, rand_pose(rng))
-    if seed >= 64:  # a sky: a random light map (odd sizes: the Lanczos resample to powers of two runs), rotated, next to the emitters
+    if 64 <= seed < 72:  # a sky: a random light map (odd sizes: the Lanczos resample to powers of two runs), rotated, next to the emitters
         hh, ww = int(rng.integers(5, 40)), int(rng.integers(8, 70))
         sky = rng.uniform(0.0, 0.6, (hh, ww, 3)).astype(np.float32)
         sky[int(rng.integers(0, hh)), int(rng.integers(0, ww))] = rng.uniform(20, 60, 3)  # a sun
@@ -180,7 +197,7 @@ def random_scene(seed):
     return sc, cam, eye
 
 
-SEEDS = list(range(72))
+SEEDS = list(range(78))
 
 
 @pytest.fixture(scope="module")
