@@ -714,7 +714,7 @@ static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int ste
                 TraceIO mio = mis_io(l, l.queues[4], cnt + 3, cursors + 3 * k + 2);
                 const bool mis_any = ctx->mis_any_hit && ctx->scene_all_opaque && !ctx->scene_has_media;
                 mio.any_as_hit = mis_any ? 1 : 0;
-                if (mis_any && ctx->nee_one_launch) {
+                if (mis_any && ctx->nee_one_launch && !ctx->count_traversal) { /* (the counting pass of bench.py wants a launch per ray kind) */
                     ProfScope ps(ctx, s, K_SHADOW, 0);
                     (use_quad(ctx, 2ll * upper_at(k)) ? rt_launch_qtrace2any : rt_launch_ptrace2any)(trace_blocks(ctx, 2ll * upper_at(k)), s,
                                                                                      ctx->sc, shadow_io(l, l.queues[3], cnt + 2, cursors + 3 * k + 1), mio);
