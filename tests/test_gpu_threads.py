@@ -78,3 +78,30 @@ def test_errors_stay_in_their_thread(cuda):
     b.start(); b.join(60)
     assert "ptr_render needs" in seen["bad"]
     assert "ptr_render needs" not in seen["good"]
+
+
+def test_destroy_with_passes_in_flight(cuda):
+    """ptr_render returns while its passes run; destroying the context (or replacing the film, or the scene) right away must
+    wait for them, not pull their buffers away"""
+    sc = common.build("knot_glass", 256, 192)
+    for what in ("destroy", "film", "scene"):
+        r = pa.Renderer(0)
+        r.upload(sc)
+        r.set_camera(sc.camera)
+        r.film_init(256, 192, 3)
+        r.render(256, pa.LI_VOLPATH)  # ~12 M paths over several lanes, not waited for
+        if what == "film":
+            r.film_init(128, 96, 3)
+            r.render(4, pa.LI_PATH)
+        elif what == "scene":
+            r.upload(sc)
+            r.render(4, pa.LI_PATH)
+        r.close()
+    with pa.Renderer(0) as r:  # the device is fine afterwards
+        r.upload(sc)
+        r.set_camera(sc.camera)
+        r.film_init(64, 48, 3)
+        r.render(4, pa.LI_PATHSAMPLED)
+        r.sync()
+        assert np.isfinite(r.image()).all()
+    sc.close()
