@@ -105,13 +105,16 @@ struct NeeToStruct {
     void put(int w, int v) const = delete; /* an index stored through put() would be converted to float: medium 1 -> 0x3f800000 */
     PD void puti(int w, int v) const { reinterpret_cast<int *>(r)[w] = v; }
     PD void put3(int w, const f3 &v) const { put(w, v.x); put(w + 1, v.y); put(w + 2, v.z); }
+    PD bool wants_p1() const { return true; }
 };
 struct NeeToPlanes {
     float *base;
     int slot;
+    bool p1; /* the light point is read only by VisibilityTester::Tr's walk (vis_tr): 9 of the record's words that a pass without walks need not store */
 #ifdef SH_STATS
     ShStats *st;
 #endif
+    PD bool wants_p1() const { return p1; }
     PD void put(int w, float v) const { base[plane_at((int)(sizeof(NeeRec) / 4), slot, w)] = v; }
     void put(int w, int v) const = delete;
     PD void puti(int w, int v) const { base[plane_at((int)(sizeof(NeeRec) / 4), slot, w)] = __int_as_float(v); }
@@ -169,9 +172,11 @@ PD int build_nee(const DScene &sc, const Ref &it, const BSDF *bsdf, float phase_
             rec.put3(NEE_W(oA), o);
             rec.put3(NEE_W(dA), d);
             rec.puti(NEE_W(medA), med);
-            rec.put3(NEE_W(p1), p1.p);
-            rec.put3(NEE_W(p1err), p1.pError);
-            rec.put3(NEE_W(p1n), p1.n);
+            if (rec.wants_p1()) {
+                rec.put3(NEE_W(p1), p1.p);
+                rec.put3(NEE_W(p1err), p1.pError);
+                rec.put3(NEE_W(p1n), p1.n);
+            }
         }
         SH_T(rec.st, SH_NEE_PUT_A);
     }

@@ -623,6 +623,7 @@ static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int ste
     prm.sample_first = first;
     prm.sample_step = step;
     prm.integrator = integrator;
+    prm.nee_p1 = 1;
     hipStream_t s = l.stream;
     const int slots = ctx->npix_local * nb;
     /* feedback: if the pass this lane ran before has completed, look at how fast it thinned out and
@@ -674,6 +675,7 @@ static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int ste
      * walk is one closest-hit query (dev_nee.h nee_resolve_traced), served by the persistent tracer like every other ray */
     const bool nee_closest = integrator == PTR_LI_VOLPATH && !ctx->scene_all_opaque && !ctx->scene_passthrough && ctx->nee_closest_ok;
     const bool walks = integrator == PTR_LI_VOLPATH && !ctx->scene_all_opaque && !nee_closest;
+    prm.nee_p1 = walks ? 1 : 0;
     int *cursors = l.counts + 4 * MAX_ITERS; /* ray-fetch cursors of the trace launches, 3 per bounce */
     auto upper_at = [&](int k) { int u = slots >> (k < 6 ? k : 6); return u < 1 ? 1 : u; };
     if (!walks && !nee_closest && ctx->merge_traces) {

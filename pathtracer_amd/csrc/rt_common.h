@@ -30,6 +30,7 @@ struct PassParams {
     int sample_first, sample_step; /* sample of slot = sample_first + (slot / npix) * sample_step */
     int integrator;
     const int *pix_map;            /* pixel of the film for each pixel of the pass, or null: the same index (ptr_film_tiles) */
+    int nee_p1;                    /* the pass resolves direct light with the in-kernel walks: k_shade stores the light point (NeeRec::p1*) too */
 };
 /* the film pixel a path slot belongs to: keys its RNG stream and places its camera ray */
 __device__ __forceinline__ int pass_pixel(const PassParams &prm, int slot) {

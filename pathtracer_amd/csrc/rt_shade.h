@@ -35,9 +35,9 @@ __device__ __forceinline__ void shade_slot(const DScene &sc, const Pipe &pp, con
     PathRec ps;
     soa_load<0, PATH_WORDS>(pp.paths, cap, slot, &ps);
 #ifdef SH_STATS
-    const NeeToPlanes rec = {reinterpret_cast<float *>(pp.nee), slot, shs};
+    const NeeToPlanes rec = {reinterpret_cast<float *>(pp.nee), slot, prm.nee_p1 != 0, shs};
 #else
-    const NeeToPlanes rec = {reinterpret_cast<float *>(pp.nee), slot};
+    const NeeToPlanes rec = {reinterpret_cast<float *>(pp.nee), slot, prm.nee_p1 != 0};
 #endif
     f3 ro(pp.ro[slot], pp.ro[cap + slot], pp.ro[2 * cap + slot]);
     f3 rd(pp.rd[slot], pp.rd[cap + slot], pp.rd[2 * cap + slot]);
