@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <system_error>
 #include <thread>
 
 namespace {
@@ -168,8 +169,14 @@ struct Builder {
         if (chunks <= 1) { fn(0, lo, hi); return; }
         std::vector<std::thread> th;
         const size_t n = hi - lo;
-        for (int c = 1; c < chunks; c++) th.emplace_back([&, c] { fn(c, lo + n * c / chunks, lo + n * (c + 1) / chunks); });
+        int started = 1;
+        for (int c = 1; c < chunks; c++) {
+            try { th.emplace_back([&, c] { fn(c, lo + n * c / chunks, lo + n * (c + 1) / chunks); }); }
+            catch (const std::system_error &) { break; } /* no more threads to be had: the caller takes the rest */
+            started++;
+        }
         fn(0, lo, lo + n / chunks);
+        for (int c = started; c < chunks; c++) fn(c, lo + n * c / chunks, lo + n * (c + 1) / chunks);
         for (std::thread &t : th) t.join();
     }
     static const int MAX_CHUNKS = 16;
@@ -297,9 +304,13 @@ struct Builder {
              * serial build's order (this node, the left subtree, the right subtree) */
             Out lo_out, hi_out;
             int32_t l_rel = 0;
-            std::thread th([&] { l_rel = build_range(lo, mid, &lb, depth + 1, lo_out, par - 1); });
+            std::thread th;
+            bool spawned = true;
+            try { th = std::thread([&] { l_rel = build_range(lo, mid, &lb, depth + 1, lo_out, par - 1); }); }
+            catch (const std::system_error &) { spawned = false; } /* no thread to be had: this one builds both halves */
             const int32_t r_rel = build_range(mid, hi, &rb, depth + 1, hi_out, par - 1);
-            th.join();
+            if (spawned) th.join();
+            else l_rel = build_range(lo, mid, &lb, depth + 1, lo_out, 0);
             l = splice(out, lo_out, l_rel);
             r = splice(out, hi_out, r_rel);
         } else {
