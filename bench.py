@@ -124,6 +124,8 @@ def main():
     ap.add_argument("--bvh", choices=["host", "device"], default="host", help="geometry BVH builder: host binned SAH, or the device LBVH (SURVEY 8f row 3)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal on one GPU: take the N > 1 code path (RCCL process group, barriers, all-reduce of the film) with a world of one rank")
     ap.add_argument("--roofline-only", action="store_true",
                     help="skip the timed region: only passes that run one at a time (what profiles/*_exclusive_* are rocprofv3 traces of)")
     args = ap.parse_args()
@@ -140,7 +142,7 @@ def main():
     from pathtracer_amd import dist as pdist
 
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         dist = pdist.init_process_group("nccl")
     else:
         torch.cuda.set_device(local_rank)

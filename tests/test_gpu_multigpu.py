@@ -85,3 +85,28 @@ def test_render_group_of_one_gpu(cuda, split):
     assert np.array_equal(smp, full[2].reshape(-1))
     assert np.array_equal(acc, full[1].reshape(-1))
     assert np.array_equal(we.reshape(-1), full[0].reshape(-1))
+
+
+def test_bench_multi_rank_path_over_rccl_with_one_rank(cuda):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, RCCL process group, barriers, the film's
+    all-reduce on the library's own device memory, the reduction of the statistics), rehearsed with a world of one rank:
+    --force-dist takes every N > 1 branch"""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "1", "--config", "0", "--steps", "2", "--warmup", "1", "--no-cpu", "--force-dist"]
+    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=250)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 100 and d["scaling"] == "weak"
+    assert d["config"]["config_index"] == 0
