@@ -142,7 +142,12 @@ def main():
     from pathtracer_amd import dist as pdist
 
     dist = None
-    if world > 1 or args.force_dist:
+    if world > 1 and os.environ.get("PTR_BENCH_REHEARSE_ON_GPU0"):
+        # rehearsal of N ranks on a one-GPU box: every rank renders on GPU 0, the collectives go over gloo (RCCL wants a GPU per rank)
+        local_rank = 0
+        torch.cuda.set_device(0)
+        dist = pdist.init_process_group("gloo")
+    elif world > 1 or args.force_dist:
         dist = pdist.init_process_group("nccl")
     else:
         torch.cuda.set_device(local_rank)

@@ -110,3 +110,30 @@ def test_bench_multi_rank_path_over_rccl_with_one_rank(cuda):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 100 and d["scaling"] == "weak"
     assert d["config"]["config_index"] == 0
+
+
+@pytest.mark.parametrize("extra", [[], ["--scaling", "strong", "--split", "tiles"]], ids=["weak_samples", "strong_tiles"])
+def test_bench_two_ranks_rehearsed_on_one_gpu(cuda, extra):
+    """two ranks as torch.distributed.run starts them, both rendering on GPU 0, collectives over gloo
+    (PTR_BENCH_REHEARSE_ON_GPU0: RCCL wants a GPU per rank): the rank > 0 branches of bench.py - sample / tile shards,
+    reductions, only rank 0 prints - with the whole-job figure counted over both ranks"""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PTR_BENCH_REHEARSE_ON_GPU0="1", PTR_PASS_SLOTS="4000000")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--config", "0", "--steps", "2", "--warmup", "1", "--no-cpu"] + extra
+    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=250, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-1000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 100
+    assert d["scaling"] == ("strong" if extra else "weak")
