@@ -123,8 +123,14 @@ __global__ void __launch_bounds__(TPB) k_raygen_only(DCamera cam, PassParams prm
  * vertices that run the surface / medium code: from the second bounce on about half of all rays
  * escape to the sky, and a shade wavefront costs the same whether 30 or 64 of its lanes hit. */
 #define MISS_CHUNK 16 /* groups of 64 queue entries a wavefront handles per reservation in the output queue */
+/* material types whose vertex is long to shade (two or more lobes, a microfacet transmission, a BSSRDF) */
+#define HEAVY_MATERIALS ((1u << MT_GLASS) | (1u << MT_TRANSLUCENT) | (1u << MT_PLASTIC) | (1u << MT_UBER) | (1u << MT_SUBSURFACE) | (1u << MT_KDSUBSURFACE) | (1u << MT_DISNEY))
+/* cls != null: the surviving vertices are compacted into TWO lists by what the shade kernel will run for them - q_hit gets the
+ * light ones (matte, mirror, metal, emitters, medium vertices), q_hit_b the heavy ones - counted in cls[0], cls[1]; k_hitq_join
+ * then puts the second list behind the first and sets hit_count, so that a shade wavefront holds vertices of one kind
+ * (north_star: rays compacted by material and alive state with wavefront ballots). */
 __global__ void __launch_bounds__(TPB) k_miss(DScene sc, Pipe pp, PassParams prm, const int *n_ptr, int n_host, const int *queue, int *q_hit,
-                                              int *hit_count, unsigned long long *ctrs) {
+                                              int *hit_count, unsigned long long *ctrs, int *q_hit_b, int *cls) {
     unsigned total = 0, miss = 0;
     const int n = n_ptr ? *n_ptr : n_host;
     const int lane = __lane_id();
@@ -135,18 +141,22 @@ __global__ void __launch_bounds__(TPB) k_miss(DScene sc, Pipe pp, PassParams prm
      * (half a million of them per bounce) to be what it waits for */
     for (long long base = (long long)wave * 64 * MISS_CHUNK; base < n; base += (long long)n_waves * 64 * MISS_CHUNK) {
         int slots[MISS_CHUNK];
-        unsigned long long masks[MISS_CHUNK];
-        int kept = 0;
+        unsigned long long masks[MISS_CHUNK], heavy_masks[MISS_CHUNK];
+        int kept = 0, kept_heavy = 0;
 #pragma unroll
         for (int c = 0; c < MISS_CHUNK; c++) {
             const long long i = base + c * 64 + lane;
-            bool keep = false;
+            bool keep = false, heavy = false;
             int slot = 0;
             if (i < n) {
                 slot = queue ? queue[i] : (int)i;
                 const int hp = pp.hprim[slot];
                 const int med = (int)pp.paths[plane_at(PATH_WORDS, slot, WORD_OF(PathRec, medium))];
                 keep = hp >= 0 || med >= 0;
+                if (cls && hp >= 0) {
+                    const int m = sc.prims[hp].material;
+                    heavy = m >= 0 && ((HEAVY_MATERIALS >> sc.mats[m].type) & 1u);
+                }
                 if (!keep) {
                     PathRec ps;
                     soa_load<0, WORD_OF(PathRec, dim)>(pp.paths, cap, slot, &ps); /* L, beta, bounces, flags */
@@ -170,20 +180,34 @@ __global__ void __launch_bounds__(TPB) k_miss(DScene sc, Pipe pp, PassParams prm
                 }
             }
             slots[c] = slot;
-            masks[c] = __ballot(keep);
+            heavy_masks[c] = __ballot(keep && heavy);
+            masks[c] = __ballot(keep && !heavy);
             kept += __popcll(masks[c]);
+            kept_heavy += __popcll(heavy_masks[c]);
         }
-        int out = 0;
-        if (lane == 0 && kept) out = atomicAdd(hit_count, kept);
+        int out = 0, out_b = 0;
+        if (lane == 0 && kept) out = atomicAdd(cls ? cls : hit_count, kept);
+        if (lane == 1 && kept_heavy) out_b = atomicAdd(cls + 1, kept_heavy); /* (kept_heavy is 0 without cls) */
         out = __shfl(out, 0, 64);
+        out_b = __shfl(out_b, 1, 64);
 #pragma unroll
         for (int c = 0; c < MISS_CHUNK; c++) {
             if ((masks[c] >> lane) & 1ull) q_hit[out + __popcll(masks[c] & ((1ull << lane) - 1ull))] = slots[c];
             out += __popcll(masks[c]);
+            if ((heavy_masks[c] >> lane) & 1ull) q_hit_b[out_b + __popcll(heavy_masks[c] & ((1ull << lane) - 1ull))] = slots[c];
+            out_b += __popcll(heavy_masks[c]);
         }
     }
     ctr_flush(ctrs, C_TOTAL, total);
     ctr_flush(ctrs, C_MISS, miss);
+}
+
+/* second half of k_miss's two-list compaction: the heavy vertices behind the light ones, and the total for the consumers */
+__global__ void __launch_bounds__(TPB) k_hitq_join(const int *cls, const int *q_b, int *q_hit, int *hit_count, int cap) {
+    const int na = cls[0], nb = cls[1];
+    for (long long j = (long long)blockIdx.x * TPB + threadIdx.x; j < nb; j += (long long)gridDim.x * TPB)
+        if (na + j < cap) q_hit[na + j] = q_b[j]; /* (na + nb <= cap: every entry is a distinct path slot) */
+    if (blockIdx.x == 0 && threadIdx.x == 0) *hit_count = na + nb;
 }
 
 /* The four queues a bounce leaves behind - surviving paths, direct-light records, shadow rays, MIS rays - from
@@ -323,13 +347,13 @@ struct ProfSpan {
  * of one overlaps the bulk of the others. */
 #define N_LANES 6 /* passes in flight (each on its own stream, ~5 GB of buffers at 16 M slots): 4 -> 6 gave +3.5 %, 8 no more */
 #define MAX_ITERS 20
-#define LANE_COUNTER_INTS (8 * MAX_ITERS)
+#define LANE_COUNTER_INTS (10 * MAX_ITERS)
 struct Lane {
     hipStream_t stream = nullptr;
     Pipe pipe;
     int *queues[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; /* ping, pong, nee, shadow, mis, binned */
     int *counts = nullptr;      /* device: [MAX_ITERS][4] = next, nee, shadow, mis; [MAX_ITERS][3] ray-fetch cursors;
-                                   [MAX_ITERS] live paths that did not end in the miss pre-pass */
+                                   [MAX_ITERS] live paths that did not end in the miss pre-pass; [MAX_ITERS][2] of them light / heavy to shade */
     int *counts_host = nullptr; /* pinned: the [MAX_ITERS][4] counts of the last finished pass */
     hipEvent_t film_done = nullptr, joined = nullptr;
     int staged_used = 0, slots_used = 0; /* of the pass last queued on this lane */
@@ -345,6 +369,7 @@ struct PtrContext {
     /* one tracer launch per bounce for {next segments, shadow rays, MIS rays} instead of three: 6 % less GPU
      * time for a pass that has the GPU to itself, 2 % more when several passes overlap (bench.py): off by default */
     bool merge_traces = false;
+    bool bin_hits = false;       /* PTR_BIN_HITS=1: k_miss compacts the vertices to shade into light and heavy materials (measured: no gain) */
     bool nee_one_launch = false; /* shadow + any-hit MIS rays of a bounce in one launch (PTR_NEE_ONE) */
     bool nee_closest_ok = true; /* PTR_NEE_CLOSEST=0: keep the in-kernel walks wherever a primitive has no material */
     bool mis_any_hit = true; /* MIS rays as any-hit rays where the result cannot tell the difference (PTR_MIS_ANY=0: never) */
@@ -568,7 +593,12 @@ static void enqueue_shade(PtrContext *ctx, Lane &l, const PassParams &prm, const
     int *hit_count = l.counts + 7 * MAX_ITERS + cslot;
     {
         ProfScope ps(ctx, s, K_MISS, 0);
-        hipLaunchKernelGGL(k_miss, dim3(stride_blocks), dim3(TPB), 0, s, ctx->sc, l.pipe, prm, n_ptr, n_host, q_cur, l.queues[5], hit_count, ctx->ctrs);
+        /* two lists by shading cost, joined (the direct-light queue is free between a bounce's resolve and the next bounce's route) */
+        int *cls = ctx->bin_hits ? l.counts + 8 * MAX_ITERS + 2 * cslot : nullptr;
+        hipLaunchKernelGGL(k_miss, dim3(stride_blocks), dim3(TPB), 0, s, ctx->sc, l.pipe, prm, n_ptr, n_host, q_cur, l.queues[5], hit_count, ctx->ctrs,
+                           l.queues[2], cls);
+        if (cls) hipLaunchKernelGGL(k_hitq_join, dim3(clampu(nblocks(n_upper), 32, 1024)), dim3(TPB), 0, s, (const int *)cls, (const int *)l.queues[2],
+                                    l.queues[5], hit_count, l.pipe.cap);
     }
     ProfScope ps(ctx, s, K_SHADE, 0);
     const int walk_i = prm.integrator == PTR_LI_VOLPATH && !ctx->scene_all_opaque ? 1 : 0;
@@ -820,6 +850,7 @@ int ptr_create(int device, PtrContext **out) {
     if (const char *e = getenv("PTR_TRACER")) ctx->tracer_mode = !strcmp(e, "quad") ? 1 : (!strcmp(e, "auto") ? 2 : 0);
     if (const char *e = getenv("PTR_QUAD_BELOW")) { long long v = atoll(e); if (v >= 0) ctx->quad_below = v; }
     if (const char *e = getenv("PTR_NEE_ONE")) ctx->nee_one_launch = atoi(e) != 0;
+    if (const char *e = getenv("PTR_BIN_HITS")) ctx->bin_hits = atoi(e) != 0;
     if (const char *e = getenv("PTR_STAGE_DIV")) { int v = atoi(e); if (v > 0) ctx->stage_div = v; }
     if (const char *e = getenv("PTR_MIS_ANY")) ctx->mis_any_hit = atoi(e) != 0;
     if (const char *e = getenv("PTR_NEE_CLOSEST")) ctx->nee_closest_ok = atoi(e) != 0;
