@@ -47,3 +47,24 @@ def test_closest_hit_queries_equal_the_walks(cuda, name):
     assert np.array_equal(a, b)
     for k in ("total_paths", "shadow_rays", "mis_rays", "surface_hits", "medium_hits", "misses", "zero_radiance"):
         assert ca[k] == cb[k], k
+
+
+@pytest.mark.parametrize("name", ["zoo", "room", "subsurface"])
+def test_material_binned_shade_queue_gives_the_same_film(cuda, name, monkeypatch):
+    """PTR_BIN_HITS=1 (k_miss compacts the vertices to shade into light and heavy materials, k_hitq_join joins the lists):
+    another order of the same vertices, the same film bit for bit"""
+    import numpy as np
+
+    films = []
+    for binned in ("0", "1"):
+        monkeypatch.setenv("PTR_BIN_HITS", binned)  # read when the context is created
+        sc = common.build(name, 96, 64)
+        with pa.Renderer(0) as r:
+            r.upload(sc)
+            r.set_camera(sc.camera)
+            for integ in (pa.LI_PATHSAMPLED, pa.LI_VOLPATH):
+                r.film_init(96, 64, 4)
+                r.render(6, integ)
+                films.append(r.film()[0].copy())
+        sc.close()
+    assert np.array_equal(films[0], films[2]) and np.array_equal(films[1], films[3])
