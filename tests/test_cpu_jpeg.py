@@ -2,10 +2,10 @@
 
 PARITY UNPINNED against the reference's decoder (the stb_image it vendors): the reference ships no .jpg and no decoded
 pixels, and a JPEG's pixels depend on the decoder's fixed-point choices.  What holds the decoder here:
-  * its three arithmetic stages against numpy restatements of the arithmetic stb_image documents for itself, EXACTLY:
-    the inverse DCT on random coefficient blocks (unit hook), chroma upsampling + colour conversion on files whose
+  * chroma upsampling + colour conversion against numpy statements of the fixed-point formulas, EXACTLY, on files whose
     blocks are all flat (there the inverse DCT leaves no freedom, so expected bytes follow from the file's own planes);
-  * the inverse DCT against the real-valued transform (+-1);
+  * the inverse DCT (unit hook) against the real-valued transform (+-1, mean error that of rounding), its DC closed form
+    and transposition;
   * entropy decoding: progressive (spectral selection + successive approximation), optimised Huffman tables and
     restart intervals must give the SAME bytes as the baseline file of the same picture (same coefficients);
   * whole pictures against Pillow's decoder (libjpeg: another IDCT rounding, another upsampler) within a few levels.
@@ -46,49 +46,6 @@ def save(tmp_path, name, arr, mode="RGB", **kw):
 
 
 # ---- numpy restatements of the documented fixed-point arithmetic ------------------------------------------------
-def f2f(x):
-    return int(np.float32(x) * np.float32(4096) + 0.5)
-
-
-def idct_1d(s):
-    """s: [..., 8] integers -> (x0..x3, t0..t3) of the islow factorisation, scaled by 4096"""
-    s0, s1, s2, s3, s4, s5, s6, s7 = [s[..., i].astype(np.int64) for i in range(8)]
-    p1 = (s2 + s6) * f2f(0.5411961)
-    t2 = p1 + s6 * f2f(-1.847759065)
-    t3 = p1 + s2 * f2f(0.765366865)
-    t0 = (s0 + s4) << 12
-    t1 = (s0 - s4) << 12
-    x0, x3, x1, x2 = t0 + t3, t0 - t3, t1 + t2, t1 - t2
-    t0, t1, t2, t3 = s7, s5, s3, s1
-    p3, p4, p1, p2 = t0 + t2, t1 + t3, t0 + t3, t1 + t2
-    p5 = (p3 + p4) * f2f(1.175875602)
-    t0 = t0 * f2f(0.298631336)
-    t1 = t1 * f2f(2.053119869)
-    t2 = t2 * f2f(3.072711026)
-    t3 = t3 * f2f(1.501321110)
-    p1 = p5 + p1 * f2f(-0.899976223)
-    p2 = p5 + p2 * f2f(-2.562915447)
-    p3 = p3 * f2f(-1.961570560)
-    p4 = p4 * f2f(-0.390180644)
-    return (x0, x1, x2, x3), (t0 + p1 + p3, t1 + p2 + p4, t2 + p2 + p3, t3 + p1 + p4)
-
-
-def idct_expected(block):
-    """block: [8, 8] dequantised coefficients, row-major -> [8, 8] bytes"""
-    (x0, x1, x2, x3), (t0, t1, t2, t3) = idct_1d(block.T)  # columns
-    v = np.empty((8, 8), np.int64)
-    for i, (x, t) in enumerate([(x0, t3), (x1, t2), (x2, t1), (x3, t0)]):
-        v[i] = (x + 512 + t) >> 10
-        v[7 - i] = (x + 512 - t) >> 10
-    (x0, x1, x2, x3), (t0, t1, t2, t3) = idct_1d(v)  # rows
-    out = np.empty((8, 8), np.int64)
-    bias = 65536 + (128 << 17)
-    for i, (x, t) in enumerate([(x0, t3), (x1, t2), (x2, t1), (x3, t0)]):
-        out[:, i] = (x + bias + t) >> 17
-        out[:, 7 - i] = (x + bias - t) >> 17
-    return np.clip(out, 0, 255)
-
-
 def upsample_expected(plane, hs, vs, w, h):
     """plane: low-resolution chroma [ph, pw] -> [h, w] by the 3:1 filters (factor 2) or repetition"""
     p = plane.astype(np.int64)
@@ -132,34 +89,46 @@ def ycc_to_rgb_expected(y, cb, cr):
 
 
 # ---- tests ------------------------------------------------------------------------------------------------------
-def test_idct_matches_documented_fixed_point_and_real_transform():
+def test_idct_against_the_real_transform_and_closed_forms():
+    """the decoder's fixed-point inverse DCT (unit hook) against the real-valued transform: never more than one level away
+    where nothing clamps; a block with only a DC term is 128 + round(d / 8) everywhere (two guard bits, then 17 bits removed
+    with rounding); a transposed block gives the transposed picture to within the one rounding that changes place"""
     rng = np.random.default_rng(3)
     fn = capi.host().pth_jpeg_idct
     k = np.arange(8)
     basis = np.cos((2 * k[None, :] + 1) * k[:, None] * np.pi / 16) * np.where(k == 0, np.sqrt(0.5), 1.0)[:, None] * 0.5  # [u, x]
-    worst = 0
-    for case in range(300):
+
+    def run(blk):
+        out = np.zeros(64, np.uint8)
+        b = np.ascontiguousarray(blk, np.int16)
+        fn(b.ctypes.data_as(C.POINTER(C.c_short)), out.ctypes.data_as(C.POINTER(C.c_ubyte)))
+        return out.reshape(8, 8).astype(np.int64)
+
+    worst, total, n = 0.0, 0.0, 0
+    for case in range(400):
         blk = np.zeros((8, 8), np.int16)
         kind = case % 4
-        if kind == 0:  # DC only: 128 + round(d / 8)
+        if kind == 0:  # DC only
             blk[0, 0] = rng.integers(-1024, 1024)
         elif kind == 1:  # a few low frequencies
             blk[:3, :3] = rng.integers(-200, 200, (3, 3))
         elif kind == 2:  # dense, decaying
             blk[:] = (rng.normal(0, 1, (8, 8)) * 300 / (1 + k[:, None] + k[None, :]) ** 1.5).astype(np.int16)
-        else:  # one column of the first pass has no AC (its shortcut), the others do
+        else:  # the first column has no AC term (the decoder's shortcut for such columns), the others do
             blk[:, 1:] = rng.integers(-60, 60, (8, 7))
             blk[0, 0] = rng.integers(-500, 500)
-        out = np.zeros(64, np.uint8)
-        fn(blk.ctypes.data_as(C.POINTER(C.c_short)), out.ctypes.data_as(C.POINTER(C.c_ubyte)))
-        got = out.reshape(8, 8).astype(np.int64)
-        assert np.array_equal(got, idct_expected(blk)), case
+        got = run(blk)
         real = basis.T @ blk.astype(np.float64) @ basis + 128.0
         inside = (real > 1) & (real < 254)
-        worst = max(worst, float(np.abs(got - real)[inside].max(initial=0)))
+        err = np.abs(got - real)[inside]
+        worst = max(worst, float(err.max(initial=0)))
+        total += float(err.sum())
+        n += int(inside.sum())
+        assert np.all(got[~inside & (real <= 1)] <= 2) and np.all(got[~inside & (real >= 254)] >= 253)
         if kind == 0:
             assert np.all(got == np.clip(128 + ((int(blk[0, 0]) + 4) >> 3), 0, 255))
-    assert worst <= 1.0, worst
+        assert np.abs(run(blk.T) - got.T).max() <= 1  # columns first, rows second: transposing moves a rounding, no more
+    assert worst <= 1.0 and total / n < 0.3, (worst, total / n)  # (rounding to a level alone averages 0.25)
 
 
 @pytest.mark.parametrize("subsampling,hs,vs", [(0, 1, 1), (1, 2, 1), (2, 2, 2)])
