@@ -982,30 +982,33 @@ struct JpegDecoder {
             }
             return true;
         }
-        int k = ss;
-        do {
-            int rs = br.decode(ac);
+        /* (run, 1) pairs: each places one new coefficient of magnitude 1 << al after `run` still-zero positions; every
+         * non-zero coefficient passed on the way takes a correction bit.  EOBn ends the new coefficients of this block and of
+         * n - 1 blocks after it: what is left of the band only takes correction bits. */
+        for (int k = ss; k <= se;) {
+            const int rs = br.decode(ac);
             if (rs < 0) return false;
-            int r = rs >> 4, s = rs & 15, value = 0;
-            if (s == 0) {
-                if (r < 15) {
-                    eob_run = (1 << r) - 1;
-                    if (r) eob_run += br.bits(r);
-                    r = 64; /* nothing new in the rest of the band: only refinements */
+            const int run = rs >> 4, size = rs & 15;
+            if (size == 0 && run < 15) {
+                eob_run = (1 << run) - 1;
+                if (run) eob_run += br.bits(run);
+                for (; k <= se; k++) {
+                    int16_t *p = &d[zz[k]];
+                    if (*p != 0) refine(br, p, bitv);
                 }
-            } else {
-                if (s != 1) return false;
-                value = br.bit() ? bitv : -bitv;
+                return true;
             }
-            while (k <= se) { /* skip r zero-valued coefficients, refining the non-zero ones on the way */
+            if (size > 1) return false;
+            /* size 1: a new coefficient, its sign comes first in the stream; size 0 with run 15 (ZRL): sixteen zero positions */
+            const int value = size ? (br.bit() ? bitv : -bitv) : 0;
+            int zeros_to_pass = run;
+            while (k <= se) {
                 int16_t *p = &d[zz[k++]];
-                if (*p != 0) refine(br, p, bitv);
-                else {
-                    if (r == 0) { *p = (int16_t)value; break; }
-                    r--;
-                }
+                if (*p != 0) { refine(br, p, bitv); continue; }
+                if (zeros_to_pass == 0) { *p = (int16_t)value; break; } /* (ZRL writes the zero that is there already) */
+                zeros_to_pass--;
             }
-        } while (k <= se);
+        }
         return true;
     }
     bool decode_scan() {
