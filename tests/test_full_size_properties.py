@@ -192,3 +192,27 @@ def test_incoherent_bounce_rays_against_oracle(big):
     assert other.sum() <= 2e-3 * h2.sum()
     assert np.array_equal(oracle.trace_occluded(no, nd, tmax) != 0, common.gpu_trace_occluded(r, no, nd, tmax) != 0)
     oracle.close()
+
+
+def test_full_frame_every_integrator_against_oracle(big):
+    """the other three integrators on the same full-size frames (the config's own one is test_full_frame_image_against_oracle)"""
+    import os
+
+    from oracle import orc
+
+    sc, r, W, H = big
+    if W * H > 1920 * 1080:
+        pytest.skip("the 4K frame is compared under its own integrator only")
+    oracle = common.oracle_of(sc)
+    for name, integ in common.INTEGRATORS.items():
+        if integ == sc.integ:
+            continue
+        r.film_init(W, H, 9)
+        r.render(1, integ)
+        img = r.image()
+        we, acc, _ = oracle.render(sc.camera, W, H, 9, 0, 1, integ, min(16, os.cpu_count() or 8))
+        ref = orc.image_of(we, acc).reshape(H, W, 3)
+        mean_rel, rmse_rel, off = common.image_stats(img, ref)
+        print("%s: mean_rel %.2e rmse_rel %.2e off %.2e" % (name, mean_rel, rmse_rel, off))
+        assert np.isfinite(img).all() and off <= 8e-3 and mean_rel <= 1e-3, (name, mean_rel, rmse_rel, off)
+    oracle.close()
