@@ -117,8 +117,9 @@ void CornellScene(Camera *camera, Float aspect, int variant) {
     /* variant & 4: the boxes in the Disney material (all five lobes on the first, diffuse + retro + clearcoat on the second) */
     MaterialDescriptor disney1 = MakeDisneyMaterial(Spectrum(.7, .35, .2), .6, 1.f, .5, 1.f, .8, .4);
     MaterialDescriptor disney2 = MakeDisneyMaterial(Spectrum(.3, .45, .7), .3, 0.f, .5, .6, .2, 0.f);
+    /* variant & 8: the boxes as CornellRoomBasic has them (white, mirror): the scene of the reference's images/cornell.png */
     InsertPrimitive(MakeBox(Translate(-3.5, 2, -width * 0.5) * RotateY(-25), 4, 4, 4), (variant & 4) ? disney1 : (variant & 1) ? glass : white);
-    InsertPrimitive(MakeBox(Translate(3.0, 4.25, -width * 0.25) * RotateY(30), 4.5, 8.5, 4.5), (variant & 4) ? disney2 : (variant & 1) ? mirror : white);
+    InsertPrimitive(MakeBox(Translate(3.0, 4.25, -width * 0.25) * RotateY(30), 4.5, 8.5, 4.5), (variant & 4) ? disney2 : (variant & 9) ? mirror : white);
     MaterialDescriptor matEm = MakeEmissive(Spectrum(0.992, 0.964, 0.390) * 6);
     InsertPrimitive(MakeDisk(Translate(0, height - 0.01, -height / 2) * RotateX(90), 0, width * 0.15, 0.f, 360), matEm);
     if (variant & 2) InsertCameraMedium(MakeMedium(Spectrum(.008), Spectrum(.01), 0)); /* CornellRoomSkull, main.cpp:851 */
