@@ -1344,57 +1344,54 @@ bool piz_huf_uncompress(const unsigned char *in, size_t n_in, std::vector<uint16
     }
     return o == n_out;
 }
-inline void piz_wdec14(uint16_t l, uint16_t h, uint16_t &a, uint16_t &b) {
-    const short ls = (short)l, hs = (short)h;
-    const int hi = hs, ai = ls + (hi & 1) + (hi >> 1);
-    a = (uint16_t)(short)ai;
-    b = (uint16_t)(short)(ai - hi);
-}
-inline void piz_wdec16(uint16_t l, uint16_t h, uint16_t &a, uint16_t &b) {
-    const int m = l, d = h;
-    const int bb = (m - (d >> 1)) & 0xffff;
-    const int aa = (d + bb - 0x8000) & 0xffff;
-    b = (uint16_t)bb;
-    a = (uint16_t)aa;
-}
-void piz_wav2_decode(uint16_t *in, int nx, int ox, int ny, int oy, uint16_t mx) {
-    const bool w14 = mx < (1 << 14);
-    const int n = nx > ny ? ny : nx;
-    int p = 1, p2;
-    while (p <= n) p <<= 1;
-    p >>= 1;
-    p2 = p;
-    p >>= 1;
-    auto dec = [&](uint16_t l, uint16_t h, uint16_t &a, uint16_t &b) { if (w14) piz_wdec14(l, h, a, b); else piz_wdec16(l, h, a, b); };
-    while (p >= 1) {
-        uint16_t *py = in, *ey = in + (ptrdiff_t)oy * (ny - p2);
-        const ptrdiff_t oy1 = (ptrdiff_t)oy * p, oy2 = (ptrdiff_t)oy * p2, ox1 = (ptrdiff_t)ox * p, ox2 = (ptrdiff_t)ox * p2;
-        uint16_t i00, i01, i10, i11;
-        for (; py <= ey; py += oy2) {
-            uint16_t *px = py, *ex = py + (ptrdiff_t)ox * (nx - p2);
-            for (; px <= ex; px += ox2) {
-                uint16_t *p01 = px + ox1, *p10 = px + oy1, *p11 = p10 + ox1;
-                dec(*px, *p10, i00, i10);
-                dec(*p01, *p11, i01, i11);
-                dec(i00, i01, *px, *p01);
-                dec(i10, i11, *p10, *p11);
-            }
-            if (nx & p) {
-                uint16_t *p10 = px + oy1;
-                dec(*px, *p10, i00, *p10);
-                *px = i00;
-            }
+/* Inverse of PIZ's two-dimensional integer wavelet over one 16-bit plane (element (x, y) at v[x * sx + y * sy]).
+ * Written from the format's definition, level by level, as two separable sweeps:
+ *   a level of step p joins samples p apart into (average, difference) pairs; going back, the pair (l, h) gives
+ *   14-bit data:  a = l + (h & 1) + (h >> 1),  b = a - h            (signed 16-bit arithmetic)
+ *   16-bit data:  b = l - (h >> 1),  a = h + b - 0x8000              (modulo 2^16)
+ * Along an axis of n samples, level p pairs (k 2p, k 2p + p) for k < n / 2p; a sample at (n / 2p) 2p is "alone" when bit p of n
+ * is set: it takes part in the other axis' sweep only.  Rows are undone before columns wherever both apply, and the two sweeps
+ * touch disjoint samples where only one applies, so each sweep can run over the whole plane before the next. */
+struct PizUnlift {
+    bool narrow; /* every value of the block fits 14 bits */
+    void operator()(uint16_t &lo, uint16_t &hi) const {
+        if (narrow) {
+            const int d = (int16_t)hi, s = (int16_t)lo + (d & 1) + (d >> 1);
+            lo = (uint16_t)(int16_t)s;
+            hi = (uint16_t)(int16_t)(s - d);
+        } else {
+            const unsigned d = hi, second = (lo - (d >> 1)) & 0xffffu, first = (d + second - 0x8000u) & 0xffffu;
+            lo = (uint16_t)first;
+            hi = (uint16_t)second;
         }
-        if (ny & p) {
-            uint16_t *px = py, *ex = py + (ptrdiff_t)ox * (nx - p2);
-            for (; px <= ex; px += ox2) {
-                uint16_t *p01 = px + ox1;
-                dec(*px, *p01, i00, *p01);
-                *px = i00;
+    }
+};
+/* the positions along an axis of n samples that the OTHER axis' sweep of level p visits: both members of every pair, then the lone one */
+static void piz_level_lines(int n, int p, std::vector<int> &lines) {
+    lines.clear();
+    const int pairs = n / (2 * p);
+    for (int k = 0; k < pairs; k++) { lines.push_back(2 * p * k); lines.push_back(2 * p * k + p); }
+    if (n & p) lines.push_back(2 * p * pairs);
+}
+void piz_wavelet_inverse(uint16_t *v, int nx, ptrdiff_t sx, int ny, ptrdiff_t sy, uint16_t max_value) {
+    const PizUnlift unlift = {max_value < (1 << 14)};
+    int top = 1;
+    while (2 * top <= (nx < ny ? nx : ny)) top *= 2; /* largest power of two <= the shorter side */
+    std::vector<int> cols, rows;
+    for (int p = top / 2; p >= 1; p /= 2) {
+        piz_level_lines(nx, p, cols);
+        piz_level_lines(ny, p, rows);
+        const int ypairs = ny / (2 * p), xpairs = nx / (2 * p);
+        for (int x : cols) /* sweep along y */
+            for (int k = 0; k < ypairs; k++) {
+                uint16_t *q = v + x * sx + (ptrdiff_t)(2 * p * k) * sy;
+                unlift(q[0], q[p * sy]);
             }
-        }
-        p2 = p;
-        p >>= 1;
+        for (int y : rows) /* sweep along x */
+            for (int k = 0; k < xpairs; k++) {
+                uint16_t *q = v + y * sy + (ptrdiff_t)(2 * p * k) * sx;
+                unlift(q[0], q[p * sx]);
+            }
     }
 }
 /* one PIZ block -> the raw scan-line layout the other compressions give (line by line, channel by channel) */
@@ -1432,7 +1429,7 @@ bool exr_unpiz(const unsigned char *src, size_t packed, const std::vector<ExrCha
     std::vector<uint16_t> buf;
     if (!piz_huf_uncompress(src + at, (size_t)len, buf, total)) return false;
     for (size_t c = 0; c < chans.size(); c++)
-        for (int j = 0; j < size[c]; j++) piz_wav2_decode(&buf[start[c] + j], w, size[c], lines, w * size[c], max_value);
+        for (int j = 0; j < size[c]; j++) piz_wavelet_inverse(&buf[start[c] + j], w, size[c], lines, (ptrdiff_t)w * size[c], max_value);
     for (size_t i = 0; i < total; i++) buf[i] = lut[buf[i]];
     raw.resize(total * 2);
     size_t o = 0;
