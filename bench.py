@@ -17,8 +17,8 @@ value = incoherent rays per second: every scene query of depth >= 1 (path segmen
 MIS rays, BSSRDF probe rays) of all ranks / wall time.  The coherent camera rays are reported beside it
 (mrays_primary), as are the closest-hit and any-hit shares of the incoherent rays.
 
-N > 1 (one rank per GPU, scene replicated, no exchange while rendering, one all-reduce of the accumulators inside
-the timed region):
+N > 1 (one rank per GPU, scene replicated, no exchange while rendering, the film assembled on rank 0 inside the timed
+region - a gather of packed tiles or a sum reduce, pathtracer_amd.dist.FilmGather):
   --scaling weak    (default) every rank renders --spp samples of every pixel: sample s -> rank s mod N
   --scaling strong  --spp samples per step in TOTAL, split over the ranks by --split tiles (8x8-pixel tiles dealt round-robin,
                     the reduced film is bit-identical to the 1-GPU film; default) or --split samples
@@ -37,6 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
+ROOFLINE_PASSES = 2  # passes of the roofline leg, each alone on the GPU (kernels_ms_exclusive_per_step divides by this)
 
 # config -> (scene family, p0, p1, width, height, samples per step, description)
 CONFIGS = {
@@ -63,9 +64,13 @@ def measured_traffic(summary, kernel, config):
     """HBM-side bytes per launch of `kernel` from the newest committed PMC summary (profiles/r*_summary.json, written by
     tools/gpu_profile.sh -> tools/prof_summary.py --json from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over
     this same command).  rocprofv3 reports KB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B, hence the factor 2
-    (MI355X_MICROARCH.md, HBM section).  None if the summary is of another config."""
+    (MI355X_MICROARCH.md, HBM section).  None if the summary is of another config, or was collected from other kernel
+    sources than this tree's (`_csrc_hash`): a stale figure is not reported."""
     if not summary or summary.get("_config", 1) != config:
         return None
+    from pathtracer_amd.capi import kernel_source_hash
+    if summary.get("_csrc_hash") != kernel_source_hash():
+        return None  # counters of other kernel sources than this tree's: stale, not reported
     try:
         k = summary[kernel]
         c = k["counters"]
@@ -225,6 +230,9 @@ def main():
     new_film()  # the timed region starts from a clean film
 
     we_t, acc_t, smp_t = pdist.film_tensors(r, dev)
+    # the whole job's film is assembled on rank 0 in tensors of its own (tiles: one gather of packed tiles; samples: one sum
+    # reduce); the ranks' own films stay as they are
+    gather = pdist.FilmGather(dist, W, H, split, dev, renderer=r) if dist is not None else None
 
     barrier()
     t0 = time.perf_counter()
@@ -233,7 +241,7 @@ def main():
     r.sync()
     if dist is not None:
         total = args.steps * (world * spp if args.scaling == "weak" else spp)
-        pdist.all_reduce_film(dist, we_t, acc_t, smp_t, total_samples=total)
+        gather.run(we_t, acc_t, smp_t, total_samples=total)
     barrier()
     dt = time.perf_counter() - t0
 
@@ -247,7 +255,7 @@ def main():
     # serialises dispatches), whereas in the timed region six passes overlap and every launch shares the GPU.
     r.profile_reset()
     r.counters_reset()
-    for _ in range(2):
+    for _ in range(ROOFLINE_PASSES):
         step()
         r.sync()
     cx = r.counters()
@@ -314,9 +322,11 @@ def main():
                        "width": W, "height": H, "bvh_nodes": bvh["nodes"], "bvh_items": bvh["items"], "bvh_bytes": bvh["bytes"],
                        "scene_upload_s": round(t_up, 3), "bvh_builder": bvh_build["builder"], "bvh_build_ms": round(bvh_build["build_ms"], 3),
                        "bvh_depth": bvh_build["depth"],
-                       "parallelism": "%s over %d GPU(s), scene replicated, one all-reduce of the accumulators" %
-                                      ("8x8-pixel tiles round-robin" if split == "tiles" else "samples round-robin", world)},
-            "value_definition": "scene queries of depth >= 1 (path segments after the camera ray + shadow + MIS + BSSRDF probe rays) per second; camera rays excluded",
+                       "parallelism": "%s over %d GPU(s), scene replicated, %s" %
+                                      ("8x8-pixel tiles round-robin" if split == "tiles" else "samples round-robin", world,
+                                       "one gather of packed tiles to rank 0" if split == "tiles" else "one sum reduce of the accumulators to rank 0")},
+            "value_definition": "scene queries of depth >= 1 (path segments after the camera ray + shadow + MIS + BSSRDF probe rays) per second; camera rays excluded "
+                                "(since round 2; round 1's `value` counted camera rays too: that figure is `mrays_all`, kept under that key in every round since)",
             "mrays_primary": None if args.roofline_only else prim_all / dt_max / 1e6,
             "mrays_secondary_closest": None if args.roofline_only else clo_all / dt_max / 1e6,
             "mrays_secondary_any": None if args.roofline_only else any_all / dt_max / 1e6,
@@ -340,7 +350,7 @@ def main():
                                "launches": sh_launches, "nee_record_fraction": sx["nee_records"] / max(1, sx["shaded_vertices"]),
                                "note": "VALU-issue bound, not bandwidth bound (DESIGN.md 4.2): the fraction prices its traffic, the time is instructions"},
             "kernels_ms": {k: round(v["total_ms"], 3) for k, v in prof.items() if v["launches"]},
-            "kernels_ms_exclusive_per_step": {k: round(v["total_ms"] / 2, 3) for k, v in profx.items() if v["launches"]},
+            "kernels_ms_exclusive_per_step": {k: round(v["total_ms"] / ROOFLINE_PASSES, 3) for k, v in profx.items() if v["launches"]},
         }
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(scene, W, H, args.integrator, args.seed)

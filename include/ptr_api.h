@@ -342,6 +342,23 @@ int ptr_film_rgb8(PtrContext *ctx, float exposure, int algorithm, unsigned char 
 int ptr_film_write(PtrContext *ctx, const float *we_rgb, const double *acc_weight, const int64_t *samples, int64_t next_sample);
 /* Device addresses of the accumulators, for an RCCL reduce across ranks (no counterpart). */
 int ptr_film_device_ptrs(PtrContext *ctx, void **we_rgb, void **acc_weight, void **samples);
+/* Gathering the film of a tile-split render without arithmetic (no counterpart): a shard's own tiles, packed.
+ * The packed film of a shard holds its tiles t = offset + k * stride back to back, 64 pixels per tile (pixels of an edge tile
+ * that lie outside the frame are zero), pixel (x, y) of tile k at entry k * 64 + (y & 7) * 8 + (x & 7): we[3 * entry],
+ * acc[entry], samples[entry].  Every shard of a `stride`-way split packs ptr_film_tiles_packed_pixels(stride) entries, so
+ * the packed films are one fixed-size gather (ncclSend / ncclRecv, all_gather) instead of an all-reduce of whole films:
+ * 1 / stride of the bytes per rank, the rank's film stays as it is, and the gathered film can be assembled any number
+ * of times.  ptr_film_tiles_pack packs THIS context's film for its current ptr_film_tiles shard; ptr_film_tiles_unpack
+ * writes the pixels of shard (tile_offset, tile_stride) from a packed film into full-frame accumulators d_out_* of the
+ * context's width x height (any device buffers, e.g. a result film kept apart from every rank's own).  Both are
+ * asynchronous on the context's stream and allocate nothing. */
+int ptr_film_tiles_packed_pixels(PtrContext *ctx, int tile_stride, int64_t *out);
+int ptr_film_tiles_pack(PtrContext *ctx, float *d_we, double *d_acc, int64_t *d_samples);
+int ptr_film_tiles_unpack(PtrContext *ctx, int tile_offset, int tile_stride, const float *d_we, const double *d_acc, const int64_t *d_samples,
+                          float *d_out_we, double *d_out_acc, int64_t *d_out_samples);
+/* d_out_samples[0 .. width*height) = value: the sample count of a sample-split render is known without a reduce
+ * (no counterpart).  Asynchronous on the context's stream. */
+int ptr_film_fill_samples(PtrContext *ctx, int64_t *d_out_samples, int64_t value);
 /* Replaces ImageStats (camera.cpp:86-125). Synchronises. */
 int ptr_counters_read(PtrContext *ctx, PtrCounters *out);
 int ptr_counters_reset(PtrContext *ctx);

@@ -130,6 +130,10 @@ HIP_SIGNATURES = {
     "ptr_film_rgb8": (C.c_int, [CTX, C.c_float, C.c_int, C.c_void_p]),
     "ptr_film_write": (C.c_int, [CTX, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "ptr_film_device_ptrs": (C.c_int, [CTX, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "ptr_film_tiles_packed_pixels": (C.c_int, [CTX, C.c_int, C.POINTER(C.c_int64)]),
+    "ptr_film_tiles_pack": (C.c_int, [CTX, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ptr_film_tiles_unpack": (C.c_int, [CTX, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ptr_film_fill_samples": (C.c_int, [CTX, C.c_void_p, C.c_int64]),
     "ptr_counters_read": (C.c_int, [CTX, C.POINTER(PtrCounters)]),
     "ptr_counters_reset": (C.c_int, [CTX]),
     "ptr_generate_rays": (C.c_int, [CTX, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -261,3 +265,17 @@ class PtrError(RuntimeError):
 def check(rc):
     if rc != PTR_OK:
         raise PtrError(rc, hip().ptr_last_error().decode("utf-8", "replace"))
+
+
+def kernel_source_hash():
+    """sha256 over the kernel sources (csrc/*, sorted by name) the built library comes from: profiles/*_summary.json records
+    it when counters are collected, and bench.py reports counter traffic only from a summary whose hash is this tree's."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "*"))):
+        if os.path.isfile(f):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]

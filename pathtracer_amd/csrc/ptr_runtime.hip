@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -303,6 +304,41 @@ __global__ void __launch_bounds__(TPB) k_film(Pipe pp, int npix, const int *pix_
     samples[p] += nbatch;
 }
 
+/* ---- gathering a tile-split film (ptr_film_tiles_pack / _unpack, include/ptr_api.h; no counterpart in the reference) ----
+ * A shard (offset, stride) owns the 8x8 tiles t = offset + k * stride of the film.  Its packed film holds those tiles back
+ * to back, 64 pixels each whatever part of a tile lies inside the frame (the rest is zero), so that a pixel's place follows
+ * from its coordinates alone: entry k * 64 + (y & 7) * 8 + (x & 7).  Streaming copies, 28 B per pixel each way. */
+__global__ void __launch_bounds__(TPB) k_film_pack_tiles(const float *we, const double *acc, const long long *smp, int width, int height, int offset,
+                                                         int stride, long long n_entries, float *p_we, double *p_acc, long long *p_smp) {
+    const long long e = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (e >= n_entries) return;
+    const int tx = (width + PTR_TILE - 1) / PTR_TILE, ty = (height + PTR_TILE - 1) / PTR_TILE;
+    const long long t = offset + (e >> 6) * stride;
+    const int x = (int)(t % tx) * PTR_TILE + (int)(e & 7), y = (int)(t / tx) * PTR_TILE + (int)((e >> 3) & 7);
+    const bool in = t < (long long)tx * ty && x < width && y < height;
+    const long long p = in ? (long long)y * width + x : 0;
+    p_we[3 * e] = in ? we[3 * p] : 0.f; p_we[3 * e + 1] = in ? we[3 * p + 1] : 0.f; p_we[3 * e + 2] = in ? we[3 * p + 2] : 0.f;
+    p_acc[e] = in ? acc[p] : 0.0;
+    p_smp[e] = in ? smp[p] : 0;
+}
+__global__ void __launch_bounds__(TPB) k_film_unpack_tiles(const float *p_we, const double *p_acc, const long long *p_smp, int width, int height, int offset,
+                                                           int stride, long long n_entries, float *we, double *acc, long long *smp) {
+    const long long e = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (e >= n_entries) return;
+    const int tx = (width + PTR_TILE - 1) / PTR_TILE, ty = (height + PTR_TILE - 1) / PTR_TILE;
+    const long long t = offset + (e >> 6) * stride;
+    const int x = (int)(t % tx) * PTR_TILE + (int)(e & 7), y = (int)(t / tx) * PTR_TILE + (int)((e >> 3) & 7);
+    if (t >= (long long)tx * ty || x >= width || y >= height) return;
+    const long long p = (long long)y * width + x;
+    we[3 * p] = p_we[3 * e]; we[3 * p + 1] = p_we[3 * e + 1]; we[3 * p + 2] = p_we[3 * e + 2];
+    acc[p] = p_acc[e];
+    smp[p] = p_smp[e];
+}
+__global__ void __launch_bounds__(TPB) k_fill_i64(long long *dst, long long n, long long value) {
+    const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (i < n) dst[i] = value;
+}
+
 /* ------------------------------------------------------------------------------------------
  * scratch of the entry point that allocates nothing (ptr_trace_closest_noalloc, include/ptr_api.h)
  *
@@ -316,6 +352,7 @@ __global__ void __launch_bounds__(TPB) k_film(Pipe pp, int npix, const int *pix_
 static __device__ __align__(256) int scratch[PTR_SCRATCH_INTS];
 #define PTR_MAX_DEVICES 64
 static int *g_scratch_ptr[PTR_MAX_DEVICES]; /* per device: where that GPU's copy of scratch[] lives */
+static std::mutex g_scratch_mu;              /* ptr_create may be called from several host threads at once */
 
 /* ------------------------------------------------------------------------------------------
  * host runtime
@@ -812,14 +849,19 @@ int ptr_create(int device, PtrContext **out) {
     HIPCHK(hipGetDeviceProperties(&prop, device));
     if (prop.warpSize != 64) return set_err(PTR_ERR_HIP, "device wavefront size is not 64 (built for gfx950)");
     if (device >= PTR_MAX_DEVICES) return set_err(PTR_ERR_LIMIT, "device index beyond PTR_MAX_DEVICES");
-    if (!g_scratch_ptr[device]) { /* once per device, with that device current (hipSetDevice above) */
-        int *p = nullptr;
-        HIPCHK(hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch)));
-        g_scratch_ptr[device] = p;
+    int *scratch_here = nullptr;
+    { /* once per device, with that device current (hipSetDevice above) */
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        if (!g_scratch_ptr[device]) {
+            int *p = nullptr;
+            HIPCHK(hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch)));
+            g_scratch_ptr[device] = p;
+        }
+        scratch_here = g_scratch_ptr[device];
     }
     PtrContext *ctx = new PtrContext();
     ctx->device = device;
-    ctx->static_scratch = g_scratch_ptr[device];
+    ctx->static_scratch = scratch_here;
     memset(&ctx->sc, 0, sizeof(ctx->sc));
     memset(&ctx->cam, 0, sizeof(ctx->cam));
     memset(ctx->prof_ms, 0, sizeof(ctx->prof_ms));
@@ -829,6 +871,17 @@ int ptr_create(int device, PtrContext **out) {
               hipMemset(ctx->ctrs, 0, CTR_REPLICAS * CTR_STRIDE * sizeof(unsigned long long)) == hipSuccess &&
               hipMalloc((void **)&ctx->api_fetch, API_FETCH_SLOTS * sizeof(int)) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&ctx->entry, hipEventDisableTiming) == hipSuccess;
+    /* The lane streams must share ONE priority (plain hipStreamCreateWithFlags).  The film kernels of consecutive passes are
+     * chained across lanes by events, in sample order (run_pass: hipStreamWaitEvent on the previous lane's film_done), and a
+     * tracer launch is a persistent grid that fills every CU (persist_blocks = CUs x PT_WAVES resident blocks) until its queue
+     * is drained.  With mixed priorities (round 2: hipStreamCreateWithPriority, alternating highest / lowest) the hardware
+     * scheduler keeps handing CUs to the high-priority lanes' persistent grids; the pass that owns the NEXT film_done event
+     * in the chain sits on a low-priority lane, gets no CU while any high-priority grid has rays left, and every
+     * high-priority pass in turn ends at a film kernel that waits for that event: the six lanes multiplexed on the
+     * GPU's four hardware queues made no progress for minutes.  At equal priority a launch waits only for launches queued
+     * before it, each of which drains (every wave of a persistent grid reaches its exit, dev_trace.h), and the chain
+     * follows the order in which ptr_render queued the passes, so it cannot close into a cycle - also with N_LANES above
+     * the queue count plus the caller's stream: streams sharing a hardware queue only serialise, in that same order. */
     for (Lane &l : ctx->lanes) {
         memset(&l.pipe, 0, sizeof(l.pipe));
         ok = ok && hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) == hipSuccess &&
@@ -1335,6 +1388,52 @@ int ptr_film_device_ptrs(PtrContext *ctx, void **we_rgb, void **acc_weight, void
     if (we_rgb) *we_rgb = ctx->we;
     if (acc_weight) *acc_weight = ctx->acc;
     if (samples) *samples = ctx->samples;
+    return PTR_OK;
+}
+
+/* entries (of 64 pixels per tile) in the packed film of one of `stride` tile shards: the same for every shard, sized for the largest */
+static long long packed_tiles(int width, int height, int stride) {
+    const long long tiles = (long long)((width + PTR_TILE - 1) / PTR_TILE) * ((height + PTR_TILE - 1) / PTR_TILE);
+    return (tiles + stride - 1) / stride;
+}
+int ptr_film_tiles_packed_pixels(PtrContext *ctx, int tile_stride, int64_t *out) {
+    if (!ctx || !out) return set_err(PTR_ERR_INVALID, "null argument");
+    if (!ctx->has_film) return set_err(PTR_ERR_STATE, "no film");
+    if (tile_stride < 1) return set_err(PTR_ERR_INVALID, "bad tile stride");
+    *out = packed_tiles(ctx->width, ctx->height, tile_stride) * PTR_TILE * PTR_TILE;
+    return PTR_OK;
+}
+int ptr_film_tiles_pack(PtrContext *ctx, float *d_we, double *d_acc, int64_t *d_samples) {
+    int rc = ctx_use(ctx);
+    if (rc) return rc;
+    if (!ctx->has_film) return set_err(PTR_ERR_STATE, "no film");
+    if (!d_we || !d_acc || !d_samples) return set_err(PTR_ERR_INVALID, "null packed buffer");
+    const long long n = packed_tiles(ctx->width, ctx->height, ctx->tile_stride) * PTR_TILE * PTR_TILE;
+    hipLaunchKernelGGL(k_film_pack_tiles, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, ctx->stream, (const float *)ctx->we, (const double *)ctx->acc,
+                       (const long long *)ctx->samples, ctx->width, ctx->height, ctx->tile_offset, ctx->tile_stride, n, d_we, d_acc, (long long *)d_samples);
+    HIPCHK(hipGetLastError());
+    return PTR_OK;
+}
+int ptr_film_tiles_unpack(PtrContext *ctx, int tile_offset, int tile_stride, const float *d_we, const double *d_acc, const int64_t *d_samples,
+                          float *d_out_we, double *d_out_acc, int64_t *d_out_samples) {
+    int rc = ctx_use(ctx);
+    if (rc) return rc;
+    if (!ctx->has_film) return set_err(PTR_ERR_STATE, "no film");
+    if (tile_stride < 1 || tile_offset < 0 || tile_offset >= tile_stride) return set_err(PTR_ERR_INVALID, "bad tile shard (offset, stride)");
+    if (!d_we || !d_acc || !d_samples || !d_out_we || !d_out_acc || !d_out_samples) return set_err(PTR_ERR_INVALID, "null buffer");
+    const long long n = packed_tiles(ctx->width, ctx->height, tile_stride) * PTR_TILE * PTR_TILE;
+    hipLaunchKernelGGL(k_film_unpack_tiles, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, ctx->stream, d_we, d_acc, (const long long *)d_samples,
+                       ctx->width, ctx->height, tile_offset, tile_stride, n, d_out_we, d_out_acc, (long long *)d_out_samples);
+    HIPCHK(hipGetLastError());
+    return PTR_OK;
+}
+int ptr_film_fill_samples(PtrContext *ctx, int64_t *d_out_samples, int64_t value) {
+    int rc = ctx_use(ctx);
+    if (rc) return rc;
+    if (!ctx->has_film) return set_err(PTR_ERR_STATE, "no film");
+    if (!d_out_samples) return set_err(PTR_ERR_INVALID, "null buffer");
+    hipLaunchKernelGGL(k_fill_i64, dim3(nblocks(ctx->npix)), dim3(TPB), 0, ctx->stream, (long long *)d_out_samples, (long long)ctx->npix, (long long)value);
+    HIPCHK(hipGetLastError());
     return PTR_OK;
 }
 

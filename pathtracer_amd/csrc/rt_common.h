@@ -9,6 +9,8 @@
 #include "dev_trace.h"
 #include <hip/hip_runtime.h>
 #include <cstddef>
+#include <cstdio>
+#include <mutex>
 
 #define TPB 256
 static_assert(TPB == LOBE_STRIDE, "the lobe columns in LDS are strided by the block size (dev_bsdf.h)");
@@ -118,6 +120,23 @@ static_assert(CX_END <= CTR_STRIDE, "a counter copy is one 128-byte line");
 #ifndef SHADE_WAVES
 #define SHADE_WAVES 2
 #endif
+
+/* More than 64 KB of dynamic LDS has to be asked for with hipFuncSetAttribute - per kernel AND per device (a RenderGroup runs
+ * several GPUs from one process, its drivers may launch from one host thread per context): `st` is the launcher's own
+ * static state, one bit per device, taken under its mutex; a failure is reported and retried at the next launch. */
+struct DynLdsOnce {
+    std::mutex mu;
+    unsigned long long done = 0;
+};
+static inline void ensure_max_dynamic_lds(DynLdsOnce &st, const void *kernel, int bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 63;
+    std::lock_guard<std::mutex> lk(st.mu);
+    if ((st.done >> dev) & 1ull) return;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) st.done |= 1ull << dev;
+    else fprintf(stderr, "pathtracer_amd: hipFuncSetAttribute(MaxDynamicSharedMemorySize, %d) on device %d: %s\n", bytes, dev, hipGetErrorString(e));
+}
 
 /* ---- launchers (one per kernel translation unit) ---- */
 struct ShadeArgs {

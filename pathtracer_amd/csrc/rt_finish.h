@@ -88,11 +88,7 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(FINISH
 template <bool SSS> static void rt_launch_finish_t(unsigned blocks, hipStream_t s, const FinishArgs &a) {
     const int lobes = a.max_lobes < 1 ? 1 : (a.max_lobes > MAX_LOBES ? MAX_LOBES : a.max_lobes);
     const size_t dyn = (size_t)lobes * LOBE_WORDS * LOBE_STRIDE * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) { /* more than 64 KB of dynamic LDS has to be asked for */
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_finish<SSS>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)(MAX_LOBES * LOBE_WORDS * LOBE_STRIDE * sizeof(float)));
-        attr_set = true;
-    }
+    static DynLdsOnce once;
+    ensure_max_dynamic_lds(once, reinterpret_cast<const void *>(&k_finish<SSS>), (int)(MAX_LOBES * LOBE_WORDS * LOBE_STRIDE * sizeof(float)));
     hipLaunchKernelGGL(k_finish<SSS>, dim3(blocks), dim3(TPB), dyn, s, a.sc, a.pp, a.prm, a.n_ptr, a.n_host, a.queue, a.walk, a.ctrs);
 }

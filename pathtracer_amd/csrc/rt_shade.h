@@ -163,12 +163,8 @@ template <int MODE> static void rt_launch_shade_t(unsigned blocks, hipStream_t s
     if (MODE == SSS_INPLACE) {
         int lobes = a.max_lobes < 1 ? 1 : (a.max_lobes > MAX_LOBES ? MAX_LOBES : a.max_lobes);
         dyn = (size_t)lobes * LOBE_WORDS * LOBE_STRIDE * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) { /* more than 64 KB of dynamic LDS has to be asked for */
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_shade<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)(MAX_LOBES * LOBE_WORDS * LOBE_STRIDE * sizeof(float)));
-            attr_set = true;
-        }
+        static DynLdsOnce once;
+        ensure_max_dynamic_lds(once, reinterpret_cast<const void *>(&k_shade<MODE>), (int)(MAX_LOBES * LOBE_WORDS * LOBE_STRIDE * sizeof(float)));
     }
     hipLaunchKernelGGL(k_shade<MODE>, dim3(blocks), dim3(TPB), dyn, s, a.sc, a.pp, a.prm, a.n_ptr, a.n_host, a.queue, a.q_next, a.q_nee, a.q_shadow,
                        a.q_mis, a.counts, a.walk, a.ctrs);

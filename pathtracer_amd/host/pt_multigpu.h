@@ -7,10 +7,12 @@
  *   PT_SPLIT_TILES    8x8-pixel tiles dealt round-robin (tile t -> GPU t mod G), every sample of a tile on one GPU
  *                     with the per-pixel RNG keys of a 1-GPU render: the reduced film is bit-identical to it for any G;
  *   PT_SPLIT_SAMPLES  sample s -> GPU s mod G (better balance on very uneven images; sums differ in rounding);
- * and the float accumulators (Pixel::we, accWeight, samples) are combined with ONE grouped RCCL all-reduce
- * (ncclGroupStart ... ncclGroupEnd: three sum reductions per GPU, 28 bytes per pixel, fused into one launch) on
- * streams the renders are already joined into, so every GPU ends up with the full film and no host sync is needed
- * between rendering and reducing.
+ * and the float accumulators (Pixel::we, accWeight, samples) are assembled on GPU 0 in a result film of their own - tiles:
+ * every GPU packs its tiles and one grouped ncclSend / ncclRecv exchange gathers them (1 / G of the film per GPU, no
+ * arithmetic); samples: ncclReduce(sum) of we and accWeight, the sample count being known - on streams the renders are
+ * already joined into, so no host sync is needed between rendering and reducing.  A GPU's own film is never written by
+ * the reduce: it can be repeated, and rendering can go on after it (the reference shows the film after every sample,
+ * main.cpp:1135-1146).
  */
 #pragma once
 #include "../../include/ptr_api.h"
@@ -32,9 +34,9 @@ int RenderGroupUpload(RenderGroup *g, const PtrFlatScene *scene);
 int RenderGroupCamera(RenderGroup *g, const PtrCamera *cam);
 int RenderGroupFilmInit(RenderGroup *g, int width, int height, uint64_t seed);
 int RenderGroupRenderSamples(RenderGroup *g, int ns, int integrator); /* asynchronous on every GPU */
-int RenderGroupReduce(RenderGroup *g);                                 /* RCCL all-reduce of the accumulators, asynchronous */
+int RenderGroupReduce(RenderGroup *g);                                 /* the group's film assembled on GPU 0 (gather of tiles / reduce of samples), asynchronous, repeatable */
 int RenderGroupSync(RenderGroup *g);
-int RenderGroupFilmRead(RenderGroup *g, float *we_rgb, double *acc_weight, int64_t *samples); /* from GPU 0, after Reduce */
+int RenderGroupFilmRead(RenderGroup *g, float *we_rgb, double *acc_weight, int64_t *samples); /* the result film of the last Reduce */
 const char *RenderGroupLastError(void);
 #ifdef __cplusplus
 }
@@ -44,6 +46,6 @@ struct Image;
 struct Camera;
 void PrepareSceneForRendering(RenderGroup *g);
 void SetupPixels(RenderGroup *g, Image *image, unsigned long long seed);
-void Render(RenderGroup *g, Image *image, Camera *camera, int ns); /* renders and reduces */
+void Render(RenderGroup *g, Image *image, Camera *camera, int ns); /* renders (asynchronous); ImageSync reduces and reads back */
 void ImageSync(RenderGroup *g, Image *image);
 #endif

@@ -132,6 +132,23 @@ class Renderer:
         capi.check(capi.hip().ptr_film_device_ptrs(self._ctx, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
+    def tiles_packed_pixels(self, stride):
+        """entries in the packed film of each of `stride` tile shards (ptr_film_tiles_packed_pixels)"""
+        n = C.c_int64(0)
+        capi.check(capi.hip().ptr_film_tiles_packed_pixels(self._ctx, int(stride), C.byref(n)))
+        return int(n.value)
+
+    def tiles_pack(self, d_we, d_acc, d_samples):
+        """this context's own tiles into packed device buffers (ptr_film_tiles_pack); asynchronous on the context's stream"""
+        capi.check(capi.hip().ptr_film_tiles_pack(self._ctx, d_we, d_acc, d_samples))
+
+    def tiles_unpack(self, offset, stride, d_we, d_acc, d_samples, d_out_we, d_out_acc, d_out_samples):
+        """the packed film of shard (offset, stride) into full-frame device accumulators (ptr_film_tiles_unpack)"""
+        capi.check(capi.hip().ptr_film_tiles_unpack(self._ctx, int(offset), int(stride), d_we, d_acc, d_samples, d_out_we, d_out_acc, d_out_samples))
+
+    def fill_samples(self, d_out_samples, value):
+        capi.check(capi.hip().ptr_film_fill_samples(self._ctx, d_out_samples, int(value)))
+
     def image(self):
         """GetPixelRGB (camera.cpp:36-51): we / accWeight, NaN -> 0."""
         we, acc, _ = self.film()

@@ -61,30 +61,100 @@ def test_tiles_combine_with_sample_shards(cuda):
     assert np.allclose(we, full[0], rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("size", [(32, 24), (37, 21)])
+@pytest.mark.parametrize("world", [2, 3])
+def test_tile_gather_of_shards_on_one_device(cuda, size, world):
+    """What RenderGroupReduce / FilmGather do for a tile split, emulated with `world` contexts on one device: every shard
+    packs its own tiles (ptr_film_tiles_pack), shard 0 scatters all packed films into a result film of its own
+    (ptr_film_tiles_unpack).  render -> gather -> gather -> render -> gather: the result equals the unsharded film bit for
+    bit every time, and no shard's own film is changed by gathering."""
+    import torch
+
+    w, h = size
+    sc = common.build("cornell_glass", w, h)
+    dev = torch.device("cuda:0")
+    rs = [pa.Renderer(0) for _ in range(world)]
+    ref = pa.Renderer(0)
+    try:
+        for k, r in enumerate(rs + [ref]):
+            r.upload(sc)
+            r.set_camera(sc.camera)
+            r.film_init(w, h, SEED)
+            if r is not ref:
+                r.tiles(k, world)
+        n = rs[0].tiles_packed_pixels(world)
+        assert n == pdist.packed_tile_pixels(w, h, world)
+        packed = [(torch.zeros(3 * n, dtype=torch.float32, device=dev), torch.zeros(n, dtype=torch.float64, device=dev),
+                   torch.zeros(n, dtype=torch.int64, device=dev)) for _ in range(world)]
+        res = (torch.full((3 * w * h,), -1.0, dtype=torch.float32, device=dev), torch.full((w * h,), -1.0, dtype=torch.float64, device=dev),
+               torch.full((w * h,), -1, dtype=torch.int64, device=dev))
+        torch.cuda.synchronize()
+
+        def gather():
+            for k, r in enumerate(rs):
+                r.tiles_pack(*[t.data_ptr() for t in packed[k]])
+                r.sync()
+            for k in range(world):
+                rs[0].tiles_unpack(k, world, *[t.data_ptr() for t in packed[k]], *[t.data_ptr() for t in res])
+            rs[0].sync()
+            return [t.cpu().numpy() for t in res]
+
+        for step, ns in enumerate((2, 3)):
+            for r in rs + [ref]:
+                r.render(ns, pa.LI_PATHSAMPLED)
+                r.sync()
+            own = [[a.copy() for a in r.film()] for r in rs]
+            full = ref.film()
+            for rep in range(2):
+                got = gather()
+                for i in range(3):
+                    assert np.array_equal(got[i].reshape(-1), full[i].reshape(-1)), (step, rep, i)
+            # the packed layout is the documented one (dist.packed_tile_index restates it)
+            for k in range(world):
+                idx = pdist.packed_tile_index(w, h, k, world)
+                pw = packed[k][0].cpu().numpy().reshape(-1, 3)
+                assert np.array_equal(pw[idx >= 0], own[k][0].reshape(-1, 3)[idx[idx >= 0]]) and not pw[idx < 0].any()
+            for r, o in zip(rs, own):
+                assert all(np.array_equal(a, b) for a, b in zip(r.film(), o))  # gathering does not touch a shard's film
+    finally:
+        for r in rs + [ref]:
+            r.close()
+
+
 @pytest.mark.parametrize("split", [0, 1])
 def test_render_group_of_one_gpu(cuda, split):
-    """libpt_multigpu.so: ncclCommInitAll + the grouped all-reduce, with one GPU in the group"""
+    """libpt_multigpu.so: ncclCommInitAll + the gather / reduce into the group's result film, with one GPU in the group.
+    Reduce twice == reduce once, and render -> reduce -> render -> reduce equals the single-context film at each step."""
     w, h = 48, 32
     sc = common.build("zoo", w, h)
-    full = _render(sc, w, h, integ=pa.LI_VOLPATH)
     m = pa.capi.multigpu()
     g = m.RenderGroupCreate(1, None, split)
     assert g, m.RenderGroupLastError()
+    we = np.zeros((w * h, 3), np.float32)
+    acc = np.zeros(w * h, np.float64)
+    smp = np.zeros(w * h, np.int64)
     try:
         assert m.RenderGroupSize(g) == 1
         C.CDLL(None).srand(1)  # the scene build draws from libc rand() like Aggregator::Wrap; Renderer.upload reseeds the same way
-        for rc in (m.RenderGroupUpload(g, sc.flat), m.RenderGroupCamera(g, C.byref(sc.camera)), m.RenderGroupFilmInit(g, w, h, SEED),
-                   m.RenderGroupRenderSamples(g, NS, pa.LI_VOLPATH), m.RenderGroupReduce(g)):
+        for rc in (m.RenderGroupUpload(g, sc.flat), m.RenderGroupCamera(g, C.byref(sc.camera)), m.RenderGroupFilmInit(g, w, h, SEED)):
             assert rc == 0, m.RenderGroupLastError()
-        we = np.zeros((w * h, 3), np.float32)
-        acc = np.zeros(w * h, np.float64)
-        smp = np.zeros(w * h, np.int64)
-        assert m.RenderGroupFilmRead(g, we.ctypes.data, acc.ctypes.data, smp.ctypes.data) == 0, m.RenderGroupLastError()
+        assert m.RenderGroupFilmRead(g, we.ctypes.data, acc.ctypes.data, smp.ctypes.data) != 0  # nothing reduced yet
+        with pa.Renderer(0) as r:
+            r.upload(sc)
+            r.set_camera(sc.camera)
+            r.film_init(w, h, SEED)
+            for ns in (2, NS - 2):
+                r.render(ns, pa.LI_VOLPATH)
+                full = [a.copy() for a in r.film()]
+                assert m.RenderGroupRenderSamples(g, ns, pa.LI_VOLPATH) == 0, m.RenderGroupLastError()
+                for rep in range(2):
+                    assert m.RenderGroupReduce(g) == 0, m.RenderGroupLastError()
+                    assert m.RenderGroupFilmRead(g, we.ctypes.data, acc.ctypes.data, smp.ctypes.data) == 0, m.RenderGroupLastError()
+                    assert np.array_equal(smp, full[2].reshape(-1))
+                    assert np.array_equal(acc, full[1].reshape(-1))
+                    assert np.array_equal(we.reshape(-1), full[0].reshape(-1))
     finally:
         m.RenderGroupFree(g)
-    assert np.array_equal(smp, full[2].reshape(-1))
-    assert np.array_equal(acc, full[1].reshape(-1))
-    assert np.array_equal(we.reshape(-1), full[0].reshape(-1))
 
 
 def test_bench_multi_rank_path_over_rccl_with_one_rank(cuda):

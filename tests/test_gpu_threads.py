@@ -14,10 +14,17 @@ pytestmark = pytest.mark.gpu
 W, H = 96, 64
 
 
+_upload_lock = threading.Lock()
+
+
 def render(name, integ, spp, out, key, barrier=None):
-    sc = common.build(name, W, H)
-    with pa.Renderer(0) as r:
+    # scene build and upload draw from the process-wide libc rand() (srand + replay in Renderer.upload, then ptr_scene_upload's
+    # own draws for the top-level tree, as Aggregator::Wrap): one thread at a time, like any host that shares rand()
+    with _upload_lock:
+        sc = common.build(name, W, H)
+        r = pa.Renderer(0)
         r.upload(sc)
+    with r:
         r.set_camera(sc.camera)
         if barrier is not None:
             barrier.wait()

@@ -48,4 +48,7 @@ if json_out:
     out = dict(summary)
     if config is not None:
         out["_config"] = config  # which bench.py --config the passes ran (bench.py only prices a kernel with traffic of its own config)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from pathtracer_amd.capi import kernel_source_hash
+    out["_csrc_hash"] = kernel_source_hash()  # the kernel sources the counters were collected from (bench.py: traffic is null when the tree differs)
     json.dump(out, open(json_out, "w"), indent=1, sort_keys=True)
