@@ -39,6 +39,10 @@ def lib():
         L.orc_bsdf_sample.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7
         L.orc_unit_eval.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.orc_film_rgb8.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p]
+        L.orc_envmap_build.restype = C.c_void_p
+        L.orc_envmap_build.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.orc_envmap_view.argtypes = [C.c_void_p, C.c_void_p] + [C.c_void_p] * 6
+        L.orc_envmap_free.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
@@ -173,4 +177,26 @@ def film_rgb8(we, acc, exposure=2.0, algorithm=1):
     rc = lib().orc_film_rgb8(acc.size, we.ctypes.data, acc.ctypes.data, C.c_float(exposure), int(algorithm), out.ctypes.data)
     if rc:
         raise ValueError("unknown tone mapping algorithm")
+    return out
+
+
+def envmap_tables(rgb, scale=(1.0, 1.0, 1.0)):
+    """The reference's light-map bring-up (orc_envmap.cpp: texture.cpp:111-260, infinite.cpp:7-39) over rgb[h, w, 3]:
+    {"dims": (width, height, nu, nv), "texels", "func", "cdf", "func_int", "marg_cdf": float32 arrays, "marg_int"}."""
+    rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+    h, w, _ = rgb.shape
+    sc3 = np.asarray(scale, dtype=np.float32)
+    e = lib().orc_envmap_build(rgb.ctypes.data, w, h, sc3.ctypes.data)
+    if not e:
+        raise ValueError("orc_envmap_build refused the map")
+    dims = (C.c_int32 * 4)()
+    ptrs = [C.POINTER(C.c_float)() for _ in range(5)]
+    mi = C.c_float()
+    lib().orc_envmap_view(e, dims, *[C.byref(p) for p in ptrs], C.byref(mi))
+    W, H, nu, nv = [int(v) for v in dims]
+    sizes = (3 * W * H, nu * nv, (nu + 1) * nv, nv, nv + 1)
+    out = {"dims": (W, H, nu, nv), "marg_int": np.float32(mi.value)}
+    for k, p, n in zip(("texels", "func", "cdf", "func_int", "marg_cdf"), ptrs, sizes):
+        out[k] = np.ctypeslib.as_array(p, (n,)).copy()
+    lib().orc_envmap_free(e)
     return out

@@ -1,6 +1,8 @@
 """SURVEY 8f row 4, device half: the light-map tables (MipMap level 0 after scaling / Lanczos resampling, the
 sin-weighted luminance table, row CDFs, row integrals, marginal CDF) built by ptr_envmap_build on the GPU against the
-host mirror's InsertLightMap - the same floats, bit for bit, for power-of-two and other sizes."""
+ORACLE's restatement of texture.cpp:111-260 / infinite.cpp:7-39 (oracle/orc_envmap.cpp; pinned by closed forms in
+tests/test_cpu_envmap_oracle.py) - the same floats, bit for bit, for power-of-two and other sizes - and, as a
+consequence, against the host mirror's InsertLightMap, which the CPU suite holds to the same oracle."""
 import ctypes as C
 
 import numpy as np
@@ -8,6 +10,7 @@ import pytest
 
 import pathtracer_amd as pa
 from pathtracer_amd import capi
+from oracle import orc
 
 pytestmark = pytest.mark.gpu
 
@@ -55,6 +58,12 @@ def test_device_tables_equal_host_tables(cuda, w, h, scale, hdr):
     img = sky(w, h, 7 + w, hdr)
     host = tables_of(img, scale, 0)
     dev = tables_of(img, scale, 1)
+    ref = orc.envmap_tables(img, scale)  # the checker: CPU restatement of the reference
+    assert ref["dims"] == dev["dims"]
+    for k in ("texels", "func", "cdf", "func_int", "marg_cdf"):
+        assert ref[k].shape == dev[k].shape, k
+        assert np.array_equal(ref[k].view(np.uint32), dev[k].view(np.uint32)), k
+    assert ref["marg_int"].view(np.uint32) == dev["marg_int"].view(np.uint32)
     assert host["dims"] == dev["dims"]
     for k in ("texels", "func", "cdf", "func_int", "marg_cdf"):
         assert host[k].shape == dev[k].shape, k
