@@ -218,7 +218,7 @@ typedef struct {
 } PtrPipelineStats;
 
 /* One entry per kernel family; filled by ptr_profile_read when profiling is on. */
-#define PTR_PROF_KERNELS 10
+#define PTR_PROF_KERNELS 11
 typedef struct {
     char name[32];
     uint64_t launches;

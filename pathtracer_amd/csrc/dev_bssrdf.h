@@ -303,75 +303,272 @@ PD int bssrdf_probe_chain(const DScene &sc, const f3 &start, const f3 &pTarget, 
     return nFound;
 }
 
-/* Sample_Sp, bssrdf.cpp:462-560 */
-PD f3 bssrdf_sample_sp(const DScene &sc, const Bssrdf &b, float u1, const f2 &u2, SI *pi, float *pdf, unsigned *probes, const LaneStack &ls) {
+/* ---- the probe chain as queued rays of the persistent tracer (round 3) --------------------------------------------
+ * In a staged bounce the chain is not walked in the vertex's lane: k_shade<SSS_BEGIN> replays a deferred vertex up to the
+ * probe segment and leaves a CHAIN RECORD, rounds of { persistent tracer over the live chains' current segments,
+ * k_sss_advance } take every chain one hit further (make_si, count / keep, next segment - the body of the loop above, one
+ * iteration per round), and the tail kernel reads the outcome.  A record is SSS_WORDS 32-bit words in tiled planes
+ * (dev_nee.h plane_at) indexed by the chain's number, so that the tracer fetches the segment and stores the hit in place. */
+enum {
+    SW_O = 0,        /* current segment: origin (3), direction (3) - what the tracer reads */
+    SW_D = 3,
+    SW_HIT = 6,      /* tracer result: primitive or -1, */
+    SW_T = 7,        /* distance (1 - ShadowEpsilon on a miss), */
+    SW_FACE = 8,     /* face */
+    SW_TARGET = 9,   /* pTarget (3) */
+    SW_SLOT = 12,    /* path slot of the vertex */
+    SW_STATE = 13,   /* SSS_LIVE while segments remain, then SSS_DONE */
+    SW_FOUND = 14,   /* hits on the probed primitive so far */
+    SW_STEPS = 15,   /* segments traced so far */
+    SW_MED = 16,     /* medium of the current segment */
+    SW_PRIM = 17,    /* the probed primitive */
+    SW_KEEP = 18,    /* PROBE_KEEP x { o (3), d (3), t, face, med }: what the first hits on it were found with */
+    SW_KEEP_WORDS = 9,
+    /* what the tail kernels need of the entry vertex (ProbeSetup below), so that they do not shade it again */
+    SW_OK = SW_KEEP + PROBE_KEEP * SW_KEEP_WORDS, /* the probe was set up (else S = 0) */
+    SW_U1,           /* the first draw, remapped: picks among the hits */
+    SW_START,        /* start of the probe segment (3) */
+    SW_B_PO = SW_START + 3, /* Bssrdf: po.p (3), frame ns ss ts (9), eta, sigma_t (3), rho (3), table index */
+    SW_B_NS = SW_B_PO + 3, SW_B_SS = SW_B_NS + 3, SW_B_TS = SW_B_SS + 3,
+    SW_B_ETA = SW_B_TS + 3,
+    SW_B_SIGT, SW_B_RHO = SW_B_SIGT + 3,
+    SW_B_TABLE = SW_B_RHO + 3,
+    SSS_WORDS
+};
+enum { SSS_LIVE = 1, SSS_DONE = 2 };
+struct ChainRef { /* a chain record: planes + number; planes == null: there is none, the chain is walked in place */
+    uint32_t *planes;
+    int j;
+    PD bool valid() const { return planes != nullptr && j >= 0; }
+    PD size_t at(int w) const { return plane_at(SSS_WORDS, j, w); }
+    PD float getf(int w) const { return __uint_as_float(planes[at(w)]); }
+    PD int geti(int w) const { return (int)planes[at(w)]; }
+    PD f3 get3(int w) const { return f3(getf(w), getf(w + 1), getf(w + 2)); }
+    PD void putf(int w, float v) const { planes[at(w)] = __float_as_uint(v); }
+    PD void puti(int w, int v) const { planes[at(w)] = (uint32_t)v; }
+    PD void put3(int w, const f3 &v) const { putf(w, v.x); putf(w + 1, v.y); putf(w + 2, v.z); }
+};
+/* the first segment of a chain (the loop above at step 0: p = start, no error bounds, no normal, no media) */
+PD void chain_begin(const ChainRef &c, int slot, int prim, const f3 &start, const f3 &pTarget) {
+    const f3 d = pTarget - start;
+    c.put3(SW_O, offset_ray_origin(start, f3(0.f), f3(0.f), d));
+    c.put3(SW_D, d);
+    c.put3(SW_TARGET, pTarget);
+    c.puti(SW_SLOT, slot);
+    c.puti(SW_STATE, SSS_LIVE);
+    c.puti(SW_FOUND, 0);
+    c.puti(SW_STEPS, 0);
+    c.puti(SW_MED, si_medium(f3(0.f), -1, -1, d));
+    c.puti(SW_PRIM, prim);
+}
+/* one iteration of the loop above for a chain whose current segment the tracer has just answered; false: the chain has ended */
+PD bool chain_advance(const DScene &sc, const ChainRef &c) {
+    const f3 o = c.get3(SW_O), d = c.get3(SW_D);
+    const int hp = c.geti(SW_HIT), steps = c.geti(SW_STEPS) + 1;
+    c.puti(SW_STEPS, steps);
+    bool live = !(is_black(d) || hp < 0) && steps < PROBE_MAX_STEPS;
+    if (live) {
+        const float t = c.getf(SW_T);
+        const int hf = c.geti(SW_FACE), med = c.geti(SW_MED);
+        SI si;
+        make_si(sc, hp, hf, o, d, t, med, &si);
+        if (hp == c.geti(SW_PRIM)) {
+            const int nFound = c.geti(SW_FOUND);
+            if (nFound < PROBE_KEEP) {
+                const int k = SW_KEEP + nFound * SW_KEEP_WORDS;
+                c.put3(k, o); c.put3(k + 3, d); c.putf(k + 6, t); c.puti(k + 7, hf); c.puti(k + 8, med);
+            }
+            c.puti(SW_FOUND, nFound + 1);
+            if (nFound + 1 > PROBE_MAX_FOUND - 1) live = false;
+        }
+        if (live) {
+            const f3 dn = c.get3(SW_TARGET) - si.p;
+            c.put3(SW_O, offset_ray_origin(si.p, si.pError, si.n, dn));
+            c.put3(SW_D, dn);
+            c.puti(SW_MED, si_medium(si.n, si.med_in, si.med_out, dn));
+        }
+    }
+    if (!live) c.puti(SW_STATE, SSS_DONE);
+    return live;
+}
+
+/* Sample_Sp up to its probe segment, bssrdf.cpp:462-505: false when the sample carries nothing (S = 0) */
+PD bool bssrdf_probe_setup(const Bssrdf &b, float &u1, const f2 &u2, f3 *start, f3 *pTarget) {
     f3 vx, vy, vz;
-    *pdf = 0;
     if (u1 < .5f) { vx = b.ss; vy = b.ts; vz = b.ns; u1 *= 2; }
     else if (u1 < .75f) { vx = b.ts; vy = b.ns; vz = b.ss; u1 = (u1 - .5f) * 4; }
     else { vx = b.ns; vy = b.ss; vz = b.ts; u1 = (u1 - .75f) * 4; }
     int ch = clampi((int)(u1 * 3), 0, 2);
     u1 = u1 * 3 - ch;
     float r = bssrdf_sample_sr(b, ch, u2.x);
-    if (r < 0) return f3(0.f);
+    if (r < 0) return false;
     float phi = 2 * kPi * u2.y;
     float rMax = bssrdf_sample_sr(b, ch, 0.999f);
-    if (r >= rMax) return f3(0.f);
+    if (r >= rMax) return false;
     float l = 2 * sqrtf(rMax * rMax - r * r);
-    f3 start = b.po_p + r * (vx * cosf(phi) + vy * sinf(phi)) - l * vz * 0.5f;
-    f3 pTarget = start + l * vz;
-    ProbeHit keep[PROBE_KEEP];
-    int nFound = bssrdf_probe_chain(sc, start, pTarget, b.po_prim, -1, pi, probes, ls, keep);
-    if (nFound == 0) return f3(0.0f);
-    int selected = clampi((int)(u1 * nFound), 0, nFound - 1);
-    if (selected < PROBE_KEEP) {
-        ProbeHit k = keep[0];
+    *start = b.po_p + r * (vx * cosf(phi) + vy * sinf(phi)) - l * vz * 0.5f;
+    *pTarget = *start + l * vz;
+    return true;
+}
+
+/* What the BSSRDF tail knows once the entry vertex has set up its probe: the BSSRDF, the remapped first draw that later picks
+ * among the chain's hits, the probe segment (ok = false: the sample carries nothing, S = 0).  main.cpp:207-211 +
+ * Sample_S / Sample_Sp up to bssrdf.cpp:505: three draws. */
+struct ProbeSetup {
+    Bssrdf b;
+    float u1;
+    f3 start, pTarget;
+    bool ok;
+};
+PD void bssrdf_setup(const DScene &sc, const BSDF &frame, const BssrdfParams &bp, const SI &po, Rng &rng, ProbeSetup *ps) {
+    bssrdf_make(sc, bp, po, frame, &ps->b);
+    ps->u1 = rng.next();
+    f2 u2 = rand2(rng);
+    ps->start = f3(0.f);
+    ps->pTarget = f3(0.f);
+    ps->ok = bssrdf_probe_setup(ps->b, ps->u1, u2, &ps->start, &ps->pTarget);
+}
+#define BSSRDF_SETUP_DRAWS 3
+/* a chain record made from a setup (k_shade<SSS_BEGIN>), and the setup read back from it (the tail kernels) */
+PD void chain_put_setup(const ChainRef &c, const DScene &sc, const ProbeSetup &ps, int slot) {
+    if (ps.ok) chain_begin(c, slot, ps.b.po_prim, ps.start, ps.pTarget);
+    else { /* a finished chain without hits; its "segment" is never traced */
+        c.puti(SW_SLOT, slot);
+        c.puti(SW_STATE, SSS_DONE);
+        c.puti(SW_FOUND, 0);
+        c.puti(SW_STEPS, 0);
+        c.puti(SW_PRIM, ps.b.po_prim);
+        c.put3(SW_O, f3(0.f));
+        c.put3(SW_D, f3(0.f));
+        c.put3(SW_TARGET, f3(0.f));
+    }
+    c.puti(SW_OK, ps.ok ? 1 : 0);
+    c.putf(SW_U1, ps.u1);
+    c.put3(SW_START, ps.start);
+    c.put3(SW_B_PO, ps.b.po_p);
+    c.put3(SW_B_NS, ps.b.ns); c.put3(SW_B_SS, ps.b.ss); c.put3(SW_B_TS, ps.b.ts);
+    c.putf(SW_B_ETA, ps.b.eta);
+    c.put3(SW_B_SIGT, ps.b.sigma_t); c.put3(SW_B_RHO, ps.b.rho);
+    c.puti(SW_B_TABLE, (int)(ps.b.t - sc.tables));
+}
+PD void chain_get_setup(const ChainRef &c, const DScene &sc, ProbeSetup *ps) {
+    ps->ok = c.geti(SW_OK) != 0;
+    ps->u1 = c.getf(SW_U1);
+    ps->start = c.get3(SW_START);
+    ps->pTarget = c.get3(SW_TARGET);
+    ps->b.po_p = c.get3(SW_B_PO);
+    ps->b.po_prim = c.geti(SW_PRIM);
+    ps->b.ns = c.get3(SW_B_NS); ps->b.ss = c.get3(SW_B_SS); ps->b.ts = c.get3(SW_B_TS);
+    ps->b.eta = c.getf(SW_B_ETA);
+    ps->b.sigma_t = c.get3(SW_B_SIGT); ps->b.rho = c.get3(SW_B_RHO);
+    ps->b.t = sc.tables + c.geti(SW_B_TABLE);
+}
+/* a record the tail can use without any traversal: the rounds finished the chain and the record keeps every hit */
+PD bool chain_settled(const ChainRef &chain) {
+    return chain.valid() && chain.geti(SW_STATE) == SSS_DONE && chain.geti(SW_FOUND) <= PROBE_KEEP;
+}
+
+/* The rest of Sample_Sp, bssrdf.cpp:506-560: the chain's outcome, the pick among its hits, pdf and Sr.
+ * chain valid: the record the tracer rounds worked on.  CAN_WALK: whatever they left undone is traversed here, in the lane -
+ * a chain still alive goes on from its current segment (the same chain_advance, one traversal per round), a pick beyond
+ * the kept hits walks the chain again up to it - and without a record the whole chain is walked as in round 2.
+ * CAN_WALK = false (k_shade<SSS_TAIL>): the caller has checked chain_settled; no traversal code is instantiated. */
+template <bool CAN_WALK>
+PD f3 bssrdf_exit_point(const DScene &sc, const ProbeSetup &ps, const ChainRef &chain, SI *pi, float *pdf, unsigned *probes, const LaneStack &ls) {
+    *pdf = 0;
+    if (!ps.ok) return f3(0.f);
+    const Bssrdf &b = ps.b;
+    int nFound;
+    if (!CAN_WALK || chain.valid()) {
+        if (CAN_WALK) {
+            while (chain.geti(SW_STATE) == SSS_LIVE) {
+                float tmax = 1 - kShadowEpsilon, b0, b1;
+                int hp = -1, hf = 0;
+                if (probes) (*probes)++;
+                const bool hit = traverse<false, false>(sc, chain.get3(SW_O), chain.get3(SW_D), tmax, hp, hf, b0, b1, nullptr, ls);
+                chain.puti(SW_HIT, hit ? hp : -1);
+                chain.putf(SW_T, tmax);
+                chain.puti(SW_FACE, hit ? hf : -1);
+                chain_advance(sc, chain);
+            }
+        }
+        nFound = chain.geti(SW_FOUND);
+        if (nFound == 0) return f3(0.0f);
+        int selected = clampi((int)(ps.u1 * nFound), 0, nFound - 1);
+        if (!CAN_WALK || selected < PROBE_KEEP) {
+            const int k = SW_KEEP + selected * SW_KEEP_WORDS;
+            make_si(sc, b.po_prim, chain.geti(k + 7), chain.get3(k), chain.get3(k + 3), chain.getf(k + 6), chain.geti(k + 8), pi);
+        } else if (CAN_WALK) bssrdf_probe_chain(sc, ps.start, ps.pTarget, b.po_prim, selected, pi, nullptr, ls);
+    } else if (CAN_WALK) {
+        ProbeHit keep[PROBE_KEEP];
+        nFound = bssrdf_probe_chain(sc, ps.start, ps.pTarget, b.po_prim, -1, pi, probes, ls, keep);
+        if (nFound == 0) return f3(0.0f);
+        int selected = clampi((int)(ps.u1 * nFound), 0, nFound - 1);
+        if (selected < PROBE_KEEP) {
+            ProbeHit k = keep[0];
 #pragma unroll
-        for (int i = 1; i < PROBE_KEEP; i++)
-            if (selected == i) k = keep[i];
-        make_si(sc, b.po_prim, k.face, k.o, k.d, k.t, k.med, pi);
-    } else bssrdf_probe_chain(sc, start, pTarget, b.po_prim, selected, pi, nullptr, ls);
+            for (int i = 1; i < PROBE_KEEP; i++)
+                if (selected == i) k = keep[i];
+            make_si(sc, b.po_prim, k.face, k.o, k.d, k.t, k.med, pi);
+        } else bssrdf_probe_chain(sc, ps.start, ps.pTarget, b.po_prim, selected, pi, nullptr, ls);
+    } else return f3(0.f); /* (not reached: !CAN_WALK takes the first branch) */
     *pdf = bssrdf_pdf_sp(b, pi->p, pi->n) / nFound;
     return bssrdf_sr(b, length(b.po_p - pi->p));
 }
 
-/* The BSSRDF tail of Li_PathSampled / Li_VolPath (main.cpp:207-228, 320-342) after the surface
- * BSDF sampled a transmission: pick the exit point, account for direct light there (added to
- * *L_extra: it follows the vertex's own direct-light term in L), sample the exit direction.
- * Returns false if the path ends. */
-PD bool bssrdf_step(const DScene &sc, BSDF &bsdf, const BssrdfParams &bp, const SI &po, Rng &rng, bool handleMedium, bool walk, f3 *L_extra,
-                    f3 &beta, int &pflags, f3 &ro, f3 &rd, int &ray_medium, NeeCtr &nctr, unsigned *probes, const LaneStack &ls) {
-    Bssrdf b;
-    bssrdf_make(sc, bp, po, bsdf, &b);
+/* exit: where the direct light at the exit point goes when it is not resolved in place - a second direct-light record,
+ * numbered like the chain, whose two rays join the bounce's shadow / MIS launches of the persistent tracer and which
+ * k_nee_resolve2 adds to L after the vertex's own term (ptr_runtime.hip).  route[j] receives the record's flags. */
+struct ExitNee {
+    float *planes; /* NEE_WORDS tiled planes indexed by chain number, or null: resolve in place */
+    int *route;
+};
+/* The BSSRDF tail of Li_PathSampled / Li_VolPath (main.cpp:207-228, 320-342) from the probe's outcome on: pick the exit
+ * point, account for direct light there (in place: added to *L_extra, which follows the vertex's own direct-light term in L;
+ * or left as a record, see ExitNee), sample the exit direction.  bsdf: this lane's lobe column and the ENTRY point's frame
+ * (`BSDF bsdf(isect)` is only emptied, main.cpp:207-228).  Returns false if the path ends; *extra_in_place tells whether
+ * *L_extra was computed here. */
+template <bool CAN_WALK>
+PD bool bssrdf_finish(const DScene &sc, BSDF &bsdf, const ProbeSetup &ps, Rng &rng, bool handleMedium, bool walk, f3 *L_extra, bool *extra_in_place,
+                      f3 &beta, int &pflags, f3 &ro, f3 &rd, int &ray_medium, NeeCtr *nctr, unsigned *probes, const LaneStack &ls, const ChainRef &chain,
+                      const ExitNee &exit) {
     SI pi;
     float pdf = 0;
     bsdf.n = 0;
-    float u1 = rng.next();
-    f2 u2 = rand2(rng);
-    f3 S = bssrdf_sample_sp(sc, b, u1, u2, &pi, &pdf, probes, ls);
+    *extra_in_place = false;
+    f3 S = bssrdf_exit_point<CAN_WALK>(sc, ps, chain, &pi, &pdf, probes, ls);
     if (!is_black(S)) { /* Sample_S, bssrdf.cpp:447-460: the exit vertex scatters through the Sw adapter lobe */
         Lobe lb;
         lobe_clear(lb);
         lb.type = BSDF_REFLECTION | BSDF_DIFFUSE;
         lb.impl = LB_BSSRDF_ADAPTER;
-        lb.C = b.eta;
+        lb.C = ps.b.eta;
         lobe_push(&bsdf, lb);
         pi.wo = pi.n;
     }
     if (is_black(S) || is_zero(pdf)) return false;
     beta *= S / pdf;
-    u2 = rand2(rng);
+    f2 u2 = rand2(rng);
     f3 u3 = rand3(rng);
-    if (sc.n_lights >= 1) {
+    if (sc.n_lights >= 1 && (!CAN_WALK || (exit.planes && chain.valid() && !walk))) {
+#ifdef SH_STATS
+        const NeeToPlanes sink = {exit.planes, chain.j, false, nullptr};
+#else
+        const NeeToPlanes sink = {exit.planes, chain.j, false};
+#endif
+        const int fl = build_nee(sc, ref_from_si(pi), &bsdf, 0, u2, u3, handleMedium, beta, false, sink);
+        exit.route[chain.j] = (fl ? ROUTE_NEE : 0) | ((fl & NEE_A) ? ROUTE_SHADOW : 0) | ((fl & NEE_B) ? ROUTE_MIS : 0);
+    } else if (CAN_WALK && sc.n_lights >= 1) {
         NeeRec r2;
         int fl = build_nee(sc, ref_from_si(pi), &bsdf, 0, u2, u3, handleMedium, beta, false, NeeToStruct{&r2});
+        *extra_in_place = true;
         if (fl) {
             if (walk) {
-                if (fl & NEE_A) nee_shadow<true>(sc, &r2, nctr, ls);
-                *L_extra = nee_mis_resolve<true>(sc, r2, nctr, ls);
+                if (fl & NEE_A) nee_shadow<true>(sc, &r2, *nctr, ls);
+                *L_extra = nee_mis_resolve<true>(sc, r2, *nctr, ls);
             } else {
-                if (fl & NEE_A) nee_shadow<false>(sc, &r2, nctr, ls);
-                *L_extra = nee_mis_resolve<false>(sc, r2, nctr, ls);
+                if (fl & NEE_A) nee_shadow<false>(sc, &r2, *nctr, ls);
+                *L_extra = nee_mis_resolve<false>(sc, r2, *nctr, ls);
             }
         }
     }
@@ -387,4 +584,13 @@ PD bool bssrdf_step(const DScene &sc, BSDF &bsdf, const BssrdfParams &bp, const 
     ray_medium = si_medium(pi.n, pi.med_in, pi.med_out, wi);
     rd = wi;
     return true;
+}
+/* the whole tail in the vertex's lane (k_finish<true>, and through it the reference's own order of events) */
+PD bool bssrdf_step(const DScene &sc, BSDF &bsdf, const BssrdfParams &bp, const SI &po, Rng &rng, bool handleMedium, bool walk, f3 *L_extra,
+                    f3 &beta, int &pflags, f3 &ro, f3 &rd, int &ray_medium, NeeCtr &nctr, unsigned *probes, const LaneStack &ls) {
+    ProbeSetup ps;
+    bssrdf_setup(sc, bsdf, bp, po, rng, &ps);
+    bool in_place;
+    return bssrdf_finish<true>(sc, bsdf, ps, rng, handleMedium, walk, L_extra, &in_place, beta, pflags, ro, rd, ray_medium, &nctr, probes, ls,
+                               ChainRef{nullptr, -1}, ExitNee{nullptr, nullptr});
 }

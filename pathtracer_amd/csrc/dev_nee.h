@@ -48,6 +48,8 @@ PD size_t plane_at(int W, int slot, int w) {
     return ((((size_t)(slot >> PLANE_TILE_SHIFT)) * W + w) << PLANE_TILE_SHIFT) | (size_t)(slot & ((1 << PLANE_TILE_SHIFT) - 1));
 }
 enum { PFL_SPECULAR = 1 };
+/* bits k_shade leaves in hprim[slot] for k_route (ptr_runtime.hip); bit q feeds queue q = counts[q] */
+enum { ROUTE_NEXT = 1, ROUTE_NEE = 2, ROUTE_SHADOW = 4, ROUTE_MIS = 8 };
 struct __attribute__((aligned(16))) PathRec {
     float L[3], beta[3];
     int bounces, flags, dim, medium;
@@ -119,6 +121,18 @@ struct NeeToPlanes {
     void put(int w, int v) const = delete;
     PD void puti(int w, int v) const { base[plane_at((int)(sizeof(NeeRec) / 4), slot, w)] = __int_as_float(v); }
     PD void put3(int w, const f3 &v) const { put(w, v.x); put(w + 1, v.y); put(w + 2, v.z); }
+};
+
+/* k_shade<SSS_BEGIN> replays a vertex only for its probe segment: the direct-light record goes nowhere */
+struct NeeToNothing {
+#ifdef SH_STATS
+    ShStats *st = nullptr;
+#endif
+    PD void put(int, float) const {}
+    void put(int w, int v) const = delete;
+    PD void puti(int, int) const {}
+    PD void put3(int, const f3 &) const {}
+    PD bool wants_p1() const { return false; }
 };
 
 struct VertexCtr { unsigned total, miss, surf, med, light, zero; };

@@ -19,11 +19,13 @@ struct VertexOut {
     int nee_flags; /* its flags (NEE_A: shadow ray, NEE_B: MIS ray) */
     bool has_extra; /* SSS only: L_extra is to be added to L after the record's own term */
     f3 L_extra;
-    bool defer;     /* SSS_DEFER only: the vertex needs the BSSRDF tail; nothing of it may be stored, the SSS pass redoes it */
+    bool defer;     /* SSS_DEFER only: the vertex sampled the transmission of a BSSRDF material: its own part is complete (L, beta with
+                       this bounce's factor, flags, RNG position, direct-light record), the tail kernels take it from there */
 };
-/* shade_vertex's SSS mode: no BSSRDF in the scene / the BSSRDF tail is traversed in place / the tail is left to another
- * launch (rt_shade.h) */
-enum { SSS_NONE = 0, SSS_INPLACE = 1, SSS_DEFER = 2 };
+/* shade_vertex's SSS mode: SSS_NONE no BSSRDF in the scene / SSS_INPLACE the BSSRDF tail is traversed in the vertex's lane
+ * (k_finish) / SSS_DEFER the vertex ends where its tail would begin and other launches continue it (rt_shade.h).  SSS_BEGIN
+ * and SSS_TAIL are roles of those launches (sss_continue below), not modes of shade_vertex. */
+enum { SSS_NONE = 0, SSS_INPLACE = 1, SSS_DEFER = 2, SSS_BEGIN = 3, SSS_TAIL = 4 };
 
 /* What a kernel that can take the subsurface branch lends to shade_vertex: the BSSRDF probe
  * segment and the direct light at the exit point are traversed in place (dev_bssrdf.h) */
@@ -32,6 +34,9 @@ struct SssCtx {
     NeeCtr *nctr;
     unsigned *probes;
     bool walk; /* VisibilityTester::Tr / IntersectTr may pass through primitives (Li_VolPath, scene not all opaque) */
+    ChainRef chain; /* this vertex's probe-chain record (SSS_BEGIN writes it, the tails read it), or {null, -1}: walk in place */
+    int slot;       /* SSS_BEGIN: the vertex's path slot, for the record */
+    ExitNee exit;   /* SSS_INPLACE: where the exit point's direct light goes if not resolved in place */
 };
 
 /* One loop iteration of Li_Direct / Li_Path / Li_PathSampled / Li_VolPath (main.cpp:72-410).
@@ -197,7 +202,7 @@ PD VertexOut shade_vertex(const DScene &sc, int integrator, Rng &rng, f3 &ro, f3
         rd = wi;
         if (!vol) ctr.surf++; /* main.cpp:319 counts before the BSSRDF tail, :229 after it */
         if (SSS == SSS_DEFER && bp.has && (flags & BSDF_TRANSMISSION)) {
-            out.defer = true;
+            out.defer = true; /* this vertex's own part ends here; the tail kernels continue it (sss_continue below) */
             return out;
         }
         if (SSS == SSS_INPLACE && bp.has && (flags & BSDF_TRANSMISSION)) {
@@ -218,3 +223,64 @@ PD VertexOut shade_vertex(const DScene &sc, int integrator, Rng &rng, f3 &ro, f3
     return out;
 }
 
+/* ---- the BSSRDF tail of a staged bounce, in kernels of its own (rt_shade.h) ----------------------------------------
+ * k_shade<SSS_DEFER> ends a vertex that sampled the transmission of a BSSRDF material after `beta *= f |cos| / pdf`
+ * (main.cpp:199-206): the path record holds L, that beta, the flags and the RNG position, the incoming ray and the hit are
+ * left in place.  sss_continue picks the path up there and runs main.cpp:207-240 - the tail, `surface_hits` under Li_VolPath,
+ * Russian roulette, the bounce count - in one of three roles:
+ *   SSS_BEGIN    set the probe up (entry interaction, material, BSSRDF, three draws) and leave it as the vertex's chain record;
+ *   SSS_TAIL     the chain is settled and the exit point's direct light goes to a record: everything is read from the chain
+ *                record, nothing is traversed.  settled = false: not such a vertex, left for
+ *   SSS_INPLACE  whatever needs a traversal in the lane; without a chain record the probe is set up here as well. */
+struct TailOut {
+    bool alive, settled, has_extra;
+    f3 L_extra;
+};
+template <int SSS>
+PD TailOut sss_continue(const DScene &sc, int integrator, Rng &rng, f3 &ro, f3 &rd, int &ray_medium, int hp, int hf, float ht, f3 &beta, int &bounces,
+                        int &pflags, VertexCtr &ctr, const SssCtx *sss, float *lobe_mem) {
+    TailOut out;
+    out.alive = false;
+    out.settled = true;
+    out.has_extra = false;
+    out.L_extra = f3(0.f);
+    const bool vol = integrator == PTR_LI_VOLPATH;
+    const bool to_record = sss->exit.planes && sss->chain.valid() && !sss->walk;
+    if (SSS == SSS_TAIL && !(chain_settled(sss->chain) && to_record)) {
+        out.settled = false;
+        return out;
+    }
+    ProbeSetup ps;
+    BSDF bsdf;
+    bsdf.lm = lobe_mem;
+    bsdf.n = 0;
+    if (SSS != SSS_BEGIN && sss->chain.valid()) {
+        chain_get_setup(sss->chain, sc, &ps);
+        bsdf.ns = ps.b.ns; bsdf.ss = ps.b.ss; bsdf.ts = ps.b.ts;
+        rng.dim += BSSRDF_SETUP_DRAWS; /* drawn when the record was made */
+    } else {
+        SI si;
+        BssrdfParams bp;
+        make_si(sc, hp, hf, ro, rd, ht, ray_medium, &si);
+        bsdf_init(&bsdf, si);
+        compute_scattering(sc, si, &bsdf, &bp);
+        bssrdf_setup(sc, bsdf, bp, si, rng, &ps);
+        if (SSS == SSS_BEGIN) {
+            chain_put_setup(sss->chain, sc, ps, sss->slot);
+            return out;
+        }
+    }
+    if (!bssrdf_finish<SSS == SSS_INPLACE>(sc, bsdf, ps, rng, vol, sss->walk, &out.L_extra, &out.has_extra, beta, pflags, ro, rd, ray_medium, sss->nctr,
+                                           sss->probes, *sss->ls, sss->chain, sss->exit))
+        return out;
+    if (vol) ctr.surf++; /* main.cpp:229 */
+    if (max_comp(beta) < 1.f && bounces > 3) {
+        float q = fmaxr((float).05, 1 - max_comp(beta));
+        float uu = rng.next();
+        if (uu < q) return out;
+        beta = beta / (1 - q);
+    }
+    bounces++;
+    out.alive = true;
+    return out;
+}

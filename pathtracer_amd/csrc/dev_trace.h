@@ -35,6 +35,7 @@ struct TraceIO {
      * w_o, w_d, w_prim, w_t = first word of origin, direction, prim result, t result (-1: none) */
     int tile_words, w_o, w_d, w_prim, w_t;
     int any_as_hit; /* any-hit launch whose result is read like a closest hit's prim word: some prim id / -1 */
+    int w_face1;    /* tiled planes, closest hit: 1 + the word that receives the face (0: the face is not stored) */
 };
 
 enum { TM_IDLE = 0, TM_TOP = 1, TM_TOPLEAF = 2, TM_GEOM = 3 };
@@ -88,6 +89,7 @@ PD void trace_io_store(const TraceIO &io, bool any, int slot, bool hit, int hp, 
         int *b = reinterpret_cast<int *>(io.prim);
         b[plane_at(io.tile_words, slot, io.w_prim)] = (any && !io.any_as_hit) ? (hit ? 1 : 0) : (hit ? hp : -1);
         if (!any && io.w_t >= 0) b[plane_at(io.tile_words, slot, io.w_t)] = __float_as_int(tmax);
+        if (!any && io.w_face1 > 0) b[plane_at(io.tile_words, slot, io.w_face1 - 1)] = hit ? hf : -1;
         return;
     }
     if (any) {

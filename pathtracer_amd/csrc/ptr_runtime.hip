@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(TPB) k_route(const int *n_ptr, const int *queu
             slots[c] = 0;
             bits[c] = 0;
             if (i < n) {
-                slots[c] = queue[i];
+                slots[c] = queue ? queue[i] : (int)i;
                 bits[c] = route[slots[c]];
             }
         }
@@ -274,6 +274,35 @@ __global__ void __launch_bounds__(TPB) k_nee_resolve(DScene sc, Pipe pp, const i
         f3 L = ld3(ps.L);
         L += Ld;
         if (rec.flags & NEE_EXTRA) L += ld3(rec.extra);
+        st3(ps.L, L);
+        soa_store<0, 3>(pp.paths, pp.cap, slot, &ps);
+    }
+    GRID_STRIDE_END
+    ctr_flush(ctrs, C_SHADOW, ctr.shadow);
+    ctr_flush(ctrs, C_MIS, ctr.mis);
+    ctr_flush(ctrs, C_ZERO, ctr.zero);
+}
+
+/* The same for the direct light at BSSRDF exit points (dev_bssrdf.h ExitNee): records numbered like the probe chains, each added
+ * to the L of its chain's path slot.  Runs after k_nee_resolve, so the term follows the entry vertex's own (main.cpp:207-228). */
+__global__ void __launch_bounds__(TPB) k_nee_resolve2(DScene sc, Pipe pp, SssChains ch, const int *n_ptr, const int *queue, unsigned long long *ctrs,
+                                                      int shadow_closest) {
+    NeeCtr ctr;
+    ctr.shadow = ctr.mis = ctr.zero = 0;
+    Pipe p2 = pp;
+    p2.nee = reinterpret_cast<uint32_t *>(ch.exit.planes);
+    GRID_STRIDE_BEGIN(n_ptr, 0)
+    if (i < n) {
+        const int j = queue[i];
+        NeeRec rec;
+        nee_load(p2, j, &rec);
+        soa_load<NEE_RES_BEGIN, NEE_RES_END>(p2.nee, p2.cap, j, &rec);
+        const f3 Ld = nee_resolve_traced(sc, rec, ctr, shadow_closest != 0);
+        const int slot = ChainRef{ch.planes, j}.geti(SW_SLOT);
+        PathRec ps;
+        soa_load<0, 3>(pp.paths, pp.cap, slot, &ps);
+        f3 L = ld3(ps.L);
+        L += Ld;
         st3(ps.L, L);
         soa_store<0, 3>(pp.paths, pp.cap, slot, &ps);
     }
@@ -368,9 +397,9 @@ static int set_err(int code, const std::string &msg) {
         if (e_ != hipSuccess) return set_err(PTR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-enum { K_RAYGEN = 0, K_TRACE, K_SHADE, K_SHADOW, K_MIS, K_RESOLVE, K_FILM, K_FINISH, K_MISS, K_MIS_ANY, K_API_TRACE = K_TRACE };
+enum { K_RAYGEN = 0, K_TRACE, K_SHADE, K_SHADOW, K_MIS, K_RESOLVE, K_FILM, K_FINISH, K_MISS, K_MIS_ANY, K_PROBE, K_API_TRACE = K_TRACE };
 static const char *kKernelNames[PTR_PROF_KERNELS] = {"raygen", "trace_closest", "shade", "nee_shadow", "nee_mis", "nee_resolve", "film",
-                                                     "finish", "miss", "nee_mis_any"};
+                                                     "finish", "miss", "nee_mis_any", "sss_probe"};
 
 struct ProfSpan {
     hipEvent_t a, b;
@@ -385,6 +414,13 @@ struct ProfSpan {
 #define N_LANES 6 /* passes in flight (each on its own stream, ~5 GB of buffers at 16 M slots): 4 -> 6 gave +3.5 %, 8 no more */
 #define MAX_ITERS 20
 #define LANE_COUNTER_INTS (10 * MAX_ITERS)
+/* BSSRDF probe chains as tracer rays (rt_shade.h): rounds per bounce, and the lane's counters for them - per bounce
+ * [0] deferred vertices, [1] chains entering round 0, [2 + r] chains entering round r + 1, [2 + SSS_ROUNDS_MAX + r] the
+ * ray-fetch cursor of round r's tracer launch */
+#define SSS_ROUNDS_MAX 12
+#define SSS_EXIT_COUNTS (2 + 2 * SSS_ROUNDS_MAX) /* [0..4): k_route's counters over the exit-point records (unused, records, shadow rays, MIS rays); [4], [5]: fetch cursors */
+#define SSS_COUNTER_STRIDE (SSS_EXIT_COUNTS + 6)
+#define SSS_COUNTER_INTS (SSS_COUNTER_STRIDE * MAX_ITERS)
 struct Lane {
     hipStream_t stream = nullptr;
     Pipe pipe;
@@ -394,7 +430,23 @@ struct Lane {
     int *counts_host = nullptr; /* pinned: the [MAX_ITERS][4] counts of the last finished pass */
     hipEvent_t film_done = nullptr, joined = nullptr;
     int staged_used = 0, slots_used = 0; /* of the pass last queued on this lane */
+    /* probe-chain records (scenes with a BSSRDF material only; allocated at the first such pass) */
+    uint32_t *sss_planes = nullptr;
+    int *sss_live[2] = {nullptr, nullptr};
+    int *sss_counts = nullptr;
+    int sss_cap = 0;
+    /* direct light at the exit points as records of their own (dev_bssrdf.h ExitNee): planes, flags per chain, the three queues */
+    float *sss_nee2 = nullptr;
+    int *sss_route = nullptr, *sss_q[3] = {nullptr, nullptr, nullptr};
 };
+
+static void lane_free_sss(Lane &l) {
+    for (void *p : {(void *)l.sss_planes, (void *)l.sss_live[0], (void *)l.sss_live[1], (void *)l.sss_counts, (void *)l.sss_nee2, (void *)l.sss_route,
+                    (void *)l.sss_q[0], (void *)l.sss_q[1], (void *)l.sss_q[2]})
+        if (p) (void)hipFree(p);
+    l.sss_planes = nullptr; l.sss_live[0] = l.sss_live[1] = nullptr; l.sss_counts = nullptr;
+    l.sss_nee2 = nullptr; l.sss_route = nullptr; l.sss_q[0] = l.sss_q[1] = l.sss_q[2] = nullptr;
+}
 
 struct PtrContext {
     int device = 0;
@@ -412,6 +464,9 @@ struct PtrContext {
     bool mis_any_hit = true; /* MIS rays as any-hit rays where the result cannot tell the difference (PTR_MIS_ANY=0: never) */
     int scene_max_lobes = MAX_LOBES;
     bool scene_has_sss = false; /* some material carries a BSSRDF: k_shade<true> / k_finish<true> */
+    int sss_rounds = 4;         /* tracer rounds per bounce for the probe chains (PTR_SSS_ROUNDS; 0: chains are walked in the tail kernel as in round 2) */
+    int sss_cap_div = 4;        /* chain records per lane = path slots / this (PTR_SSS_CAP_DIV) */
+    bool sss_exit_records = true; /* direct light at the exit points through the tracer's launches (PTR_SSS_EXIT=0: resolved in the tail kernel) */
     /* Which persistent tracer a launch uses.  One ray per lane (dev_trace.h) has the higher throughput once the GPU is full
      * (r02, 14.4 M incoherent rays: 3.8 ms against 5.7 ms); four lanes per ray (dev_qtrace.h) has a quarter of the rays in
      * flight, a third of the instructions per step and no scratch, and ends a small launch sooner (1.8 M rays: 1.04 ms
@@ -499,6 +554,8 @@ static void free_film(PtrContext *ctx) {
         for (void *p : ptrs)
             if (p) (void)hipFree(p);
         if (l.counts_host) (void)hipHostFree(l.counts_host);
+        lane_free_sss(l);
+        l.sss_cap = 0;
         memset(&l.pipe, 0, sizeof(l.pipe));
         for (int q = 0; q < 6; q++) l.queues[q] = nullptr;
         l.counts = nullptr;
@@ -622,6 +679,49 @@ static TraceIO mis_io(const Lane &l, const int *queue, const int *n_ptr, int *cu
     io.counter = cursor;
     return io;
 }
+/* The probe chains of the bounce's deferred vertices as rays of the persistent tracer (rt_shade.h, dev_bssrdf.h): the begin
+ * kernel numbers the chains and leaves their first segments, then sss_rounds times { tracer over the live chains, advance }.
+ * a.chains is filled in for the tail kernel that follows.  The lane's SSS counters must be zero (run_pass). */
+/* Direct light at the exit points as records of the tracer's launches?  Not where its rays may pass through primitives (the
+ * in-kernel walks: Li_VolPath in a scene that is not all opaque), nor with the merged three-kind launch (PTR_MERGE). */
+static bool exit_records(const PtrContext *ctx, const Lane &l, int integrator) {
+    return ctx->scene_has_sss && ctx->sss_rounds > 0 && l.sss_planes && l.sss_nee2 && !ctx->merge_traces &&
+           !(integrator == PTR_LI_VOLPATH && !ctx->scene_all_opaque);
+}
+/* the rays of the exit-point records (queue / count written by the second k_route of the bounce) */
+static TraceIO exit_io(const Lane &l, int cslot, bool mis) {
+    int *cnt2 = l.sss_counts + SSS_COUNTER_STRIDE * cslot + SSS_EXIT_COUNTS;
+    TraceIO io;
+    memset(&io, 0, sizeof(io));
+    io.queue = l.sss_q[mis ? 2 : 1]; io.n_ptr = cnt2 + (mis ? 3 : 2);
+    io.tile_words = NEE_WORDS;
+    io.o = (const char *)l.sss_nee2; io.w_o = mis ? WORD_OF(NeeRec, oB) : WORD_OF(NeeRec, oA); io.w_d = mis ? WORD_OF(NeeRec, dB) : WORD_OF(NeeRec, dA);
+    io.tmax_const = mis ? FLT_MAX : 1 - 0.0001f;
+    io.prim = (char *)l.sss_nee2; io.w_prim = mis ? WORD_OF(NeeRec, hitB) : WORD_OF(NeeRec, occA); io.w_t = mis ? WORD_OF(NeeRec, tB) : -1;
+    io.counter = cnt2 + (mis ? 5 : 4);
+    return io;
+}
+static void enqueue_probe_chains(PtrContext *ctx, Lane &l, ShadeArgs &a, int n_upper, int cslot, unsigned tail_blocks) {
+    hipStream_t s = l.stream;
+    int *cnt = l.sss_counts + SSS_COUNTER_STRIDE * cslot;
+    a.chains = SssChains{l.sss_planes, l.sss_cap, cnt + 0, cnt + 1, ExitNee{exit_records(ctx, l, a.prm.integrator) ? l.sss_nee2 : nullptr, l.sss_route}};
+    rt_launch_shade_begin(tail_blocks, s, a);
+    const int upper = n_upper < l.sss_cap ? n_upper : l.sss_cap;
+    for (int r = 0; r < ctx->sss_rounds; r++) {
+        const int *n_ptr = cnt + 1 + r;
+        const int *live_in = r == 0 ? nullptr : l.sss_live[(r - 1) & 1];
+        TraceIO io;
+        memset(&io, 0, sizeof(io));
+        io.queue = live_in; io.n_ptr = n_ptr;
+        io.tile_words = SSS_WORDS;
+        io.o = (const char *)l.sss_planes; io.w_o = SW_O; io.w_d = SW_D;
+        io.tmax_const = 1 - 0.0001f; /* 1 - ShadowEpsilon: Interaction::SpawnRayTo (interaction.cpp:12-16) */
+        io.prim = (char *)l.sss_planes; io.w_prim = SW_HIT; io.w_t = SW_T; io.w_face1 = SW_FACE + 1;
+        io.counter = cnt + 2 + SSS_ROUNDS_MAX + r;
+        launch_ptrace(ctx, s, io, upper, false, false, K_PROBE);
+        rt_launch_sss_advance(clampu(nblocks(upper), 32, 2048), s, ctx->sc, a.chains, n_ptr, live_in, l.sss_live[r & 1], cnt + 2 + r, ctx->ctrs);
+    }
+}
 static void enqueue_shade(PtrContext *ctx, Lane &l, const PassParams &prm, const int *n_ptr, int n_host, int n_upper, const int *q_cur, int *q_next,
                           int cslot) {
     hipStream_t s = l.stream;
@@ -639,13 +739,33 @@ static void enqueue_shade(PtrContext *ctx, Lane &l, const PassParams &prm, const
     }
     ProfScope ps(ctx, s, K_SHADE, 0);
     const int walk_i = prm.integrator == PTR_LI_VOLPATH && !ctx->scene_all_opaque ? 1 : 0;
-    const ShadeArgs a = {ctx->sc, l.pipe, prm, hit_count, 0, l.queues[5], q_next, l.queues[2], l.queues[3], l.queues[4], cnt, walk_i, ctx->scene_max_lobes, ctx->ctrs};
+    ShadeArgs a = {ctx->sc, l.pipe, prm, hit_count, 0, l.queues[5], SssChains{nullptr, 0, nullptr, nullptr}, walk_i, ctx->scene_max_lobes, ctx->ctrs};
     if (ctx->scene_has_sss) { /* everything but the BSSRDF tails, then the tails as a dense list (rt_shade.h) */
         rt_launch_shade_defer(stride_blocks, s, a);
-        rt_launch_shade_sss(clampu(nblocks(n_upper) / 4 + 1, 32, 2048), s, a);
+        const unsigned tail_blocks = clampu(nblocks(n_upper) / 4 + 1, 32, 2048);
+        if (l.sss_planes && ctx->sss_rounds > 0) {
+            enqueue_probe_chains(ctx, l, a, n_upper, cslot, tail_blocks);
+            if (a.chains.exit.planes) rt_launch_shade_tail(tail_blocks, s, a); /* settled chains: no traversal; the rest stays deferred */
+        }
+        rt_launch_shade_sss(tail_blocks, s, a);
     } else rt_launch_shade(stride_blocks, s, a);
     hipLaunchKernelGGL(k_route, dim3(clampu(nblocks((n_upper + ROUTE_CHUNK - 1) / ROUTE_CHUNK), 32, 2048)), dim3(TPB), 0, s, (const int *)hit_count,
                        (const int *)l.queues[5], (const int *)l.pipe.hprim, q_next, l.queues[2], l.queues[3], l.queues[4], cnt);
+    if (a.chains.exit.planes) { /* the queues of the exit-point records, from the flags the tail kernel left per chain */
+        int *scnt = l.sss_counts + SSS_COUNTER_STRIDE * cslot;
+        const int upper = n_upper < l.sss_cap ? n_upper : l.sss_cap;
+        hipLaunchKernelGGL(k_route, dim3(clampu(nblocks((upper + ROUTE_CHUNK - 1) / ROUTE_CHUNK), 32, 2048)), dim3(TPB), 0, s, (const int *)(scnt + 1),
+                           (const int *)nullptr, (const int *)l.sss_route, l.sss_live[0], l.sss_q[0], l.sss_q[1], l.sss_q[2], scnt + SSS_EXIT_COUNTS);
+    }
+}
+/* the exit-point records of the bounce summed into L (after enqueue_resolve: their term follows the vertex's own) */
+static void enqueue_resolve2(PtrContext *ctx, Lane &l, int n_upper, int cslot, int integrator) {
+    int *scnt = l.sss_counts + SSS_COUNTER_STRIDE * cslot;
+    const int upper = n_upper < l.sss_cap ? n_upper : l.sss_cap;
+    ProfScope ps(ctx, l.stream, K_RESOLVE, 0);
+    const SssChains ch = {l.sss_planes, l.sss_cap, scnt, scnt + 1, ExitNee{l.sss_nee2, l.sss_route}};
+    hipLaunchKernelGGL(k_nee_resolve2, dim3(clampu(nblocks(upper), 32, 2048)), dim3(TPB), 0, l.stream, ctx->sc, l.pipe, ch, (const int *)(scnt + SSS_EXIT_COUNTS + 1),
+                       (const int *)l.sss_q[0], ctx->ctrs, 0);
 }
 /* direct light of the bounce when a shadow / MIS ray may pass through primitives (Li_VolPath with
  * medium boundaries or emitters): the walks of VisibilityTester::Tr / IntersectTr run in-kernel */
@@ -717,6 +837,26 @@ static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int ste
     }
     const size_t cbytes = (size_t)LANE_COUNTER_INTS * sizeof(int);
     HIPCHK(hipMemsetAsync(l.counts, 0, cbytes, s));
+    if (ctx->scene_has_sss && ctx->sss_rounds > 0 && !l.sss_planes && l.sss_cap == 0) {
+        /* first pass of a scene with a BSSRDF material on this lane: room for one chain record per sss_cap_div path slots
+         * (vertices beyond that walk their chain in the tail kernel); if the memory is not there, every vertex does */
+        const size_t want = ((((size_t)l.pipe.cap / ctx->sss_cap_div) >> PLANE_TILE_SHIFT) + 1) << PLANE_TILE_SHIFT;
+        hipError_t e = hipMalloc((void **)&l.sss_planes, want * SSS_WORDS * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc((void **)&l.sss_live[0], want * sizeof(int));
+        if (e == hipSuccess) e = hipMalloc((void **)&l.sss_live[1], want * sizeof(int));
+        if (e == hipSuccess) e = hipMalloc((void **)&l.sss_counts, SSS_COUNTER_INTS * sizeof(int));
+        if (e == hipSuccess && ctx->sss_exit_records) {
+            e = hipMalloc((void **)&l.sss_nee2, want * sizeof(NeeRec));
+            if (e == hipSuccess) e = hipMalloc((void **)&l.sss_route, want * sizeof(int));
+            for (int q = 0; q < 3 && e == hipSuccess; q++) e = hipMalloc((void **)&l.sss_q[q], want * sizeof(int));
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            lane_free_sss(l);
+            l.sss_cap = -1; /* do not try again for these pass buffers */
+        } else l.sss_cap = (int)want;
+    }
+    if (l.sss_counts) HIPCHK(hipMemsetAsync(l.sss_counts, 0, SSS_COUNTER_INTS * sizeof(int), s));
     {
         ProfScope ps(ctx, s, K_RAYGEN, (uint64_t)slots);
         hipLaunchKernelGGL(k_raygen, dim3(nblocks(slots)), dim3(TPB), 0, s, ctx->sc, ctx->cam, l.pipe, prm, slots);
@@ -787,11 +927,34 @@ static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int ste
                     ProfScope ps(ctx, s, K_SHADOW, 0);
                     (use_quad(ctx, 2ll * upper_at(k)) ? rt_launch_qtrace2any : rt_launch_ptrace2any)(trace_blocks(ctx, 2ll * upper_at(k)), s,
                                                                                      ctx->sc, shadow_io(l, l.queues[3], cnt + 2, cursors + 3 * k + 1), mio);
+                } else if (exit_records(ctx, l, integrator) && !ctx->count_traversal) {
+                    /* scenes with a BSSRDF material: the rays of the exit-point records ride in the same launches (any hit + any hit
+                     * in one TwoAny launch; a closest-hit MIS launch gets a second launch for them) */
+                    TraceIO mio2 = exit_io(l, k, true);
+                    mio2.any_as_hit = mis_any ? 1 : 0;
+                    {
+                        ProfScope ps(ctx, s, K_SHADOW, 0);
+                        rt_launch_ptrace2any(trace_blocks(ctx, 2ll * upper_at(k)), s, ctx->sc, shadow_io(l, l.queues[3], cnt + 2, cursors + 3 * k + 1), exit_io(l, k, false));
+                    }
+                    if (mis_any) {
+                        ProfScope ps(ctx, s, K_MIS_ANY, 0);
+                        rt_launch_ptrace2any(trace_blocks(ctx, 2ll * upper_at(k)), s, ctx->sc, mio, mio2);
+                    } else {
+                        launch_ptrace(ctx, s, mio, upper_at(k), false, false, K_MIS, est[k][2]);
+                        launch_ptrace(ctx, s, mio2, upper_at(k), false, false, K_MIS);
+                    }
                 } else {
                 launch_ptrace(ctx, s, shadow_io(l, l.queues[3], cnt + 2, cursors + 3 * k + 1, nee_closest), upper_at(k), !nee_closest, nee_closest && ctx->count_traversal, K_SHADOW, est[k][1]);
                 launch_ptrace(ctx, s, mio, upper_at(k), mis_any, ctx->count_traversal, mis_any ? K_MIS_ANY : K_MIS, est[k][2]);
+                if (exit_records(ctx, l, integrator)) { /* (counting pass: a launch per ray kind) */
+                    TraceIO mio2 = exit_io(l, k, true);
+                    mio2.any_as_hit = mis_any ? 1 : 0;
+                    launch_ptrace(ctx, s, exit_io(l, k, false), upper_at(k), true, false, K_SHADOW);
+                    launch_ptrace(ctx, s, mio2, upper_at(k), mis_any, ctx->count_traversal, mis_any ? K_MIS_ANY : K_MIS);
+                }
                 }
                 enqueue_resolve(ctx, l, upper_at(k), k, nee_closest);
+                if (exit_records(ctx, l, integrator)) enqueue_resolve2(ctx, l, upper_at(k), k, integrator);
             }
             STAGE_CHECK("direct light");
             q_cur = q_next;
@@ -907,6 +1070,9 @@ int ptr_create(int device, PtrContext **out) {
     if (const char *e = getenv("PTR_STAGE_DIV")) { int v = atoi(e); if (v > 0) ctx->stage_div = v; }
     if (const char *e = getenv("PTR_MIS_ANY")) ctx->mis_any_hit = atoi(e) != 0;
     if (const char *e = getenv("PTR_NEE_CLOSEST")) ctx->nee_closest_ok = atoi(e) != 0;
+    if (const char *e = getenv("PTR_SSS_ROUNDS")) { int v = atoi(e); if (v >= 0) ctx->sss_rounds = v > SSS_ROUNDS_MAX ? SSS_ROUNDS_MAX : v; }
+    if (const char *e = getenv("PTR_SSS_CAP_DIV")) { int v = atoi(e); if (v >= 1) ctx->sss_cap_div = v; }
+    if (const char *e = getenv("PTR_SSS_EXIT")) ctx->sss_exit_records = atoi(e) != 0;
     if (const char *e = getenv("PTR_SPREAD")) { /* tuning experiments */
         int v = atoi(e);
         if (v > 0) ctx->spread = v;
@@ -1054,6 +1220,8 @@ int ptr_scene_upload_built(PtrContext *ctx, const PtrBuiltScene *built) {
     if (rc) return rc;
     if (!built) return set_err(PTR_ERR_INVALID, "null built scene");
     const HostScene &hs = built->hs;
+    if (!hs.tables.empty() && hs.prims.size() >= (size_t)1 << 24)
+        return set_err(PTR_ERR_LIMIT, "a scene with a BSSRDF material may hold at most 2^24 primitives (the deferred vertices' hit word, rt_shade.h)");
     if ((rc = sync_all(ctx))) return rc;
     free_scene(ctx);
     DScene sc;
@@ -1603,6 +1771,19 @@ int ptr_profile_read(PtrContext *ctx, PtrKernelProfile *out, int max_entries, in
         out[i].items = ctx->prof_items[i];
     }
     if (n_out) *n_out = n;
+    return PTR_OK;
+}
+/* diagnostic (tools/gpu_sss_rounds.py): the probe-chain counters of the pass last run on lane `lane`, SSS_COUNTER_STRIDE ints
+ * per staged bounce - deferred vertices, chains entering round 0, chains entering round r + 1 ... */
+int ptr_debug_sss_counts(PtrContext *ctx, int lane, int *out, int n_ints, int *stride) {
+    int rc = ctx_use(ctx);
+    if (rc) return rc;
+    if (lane < 0 || lane >= N_LANES || !out) return set_err(PTR_ERR_INVALID, "bad lane");
+    if ((rc = sync_all(ctx))) return rc;
+    if (stride) *stride = SSS_COUNTER_STRIDE;
+    if (!ctx->lanes[lane].sss_counts) return set_err(PTR_ERR_STATE, "no probe-chain buffers on this lane");
+    const int n = n_ints < SSS_COUNTER_INTS ? n_ints : SSS_COUNTER_INTS;
+    HIPCHK(hipMemcpy(out, ctx->lanes[lane].sss_counts, n * sizeof(int), hipMemcpyDeviceToHost));
     return PTR_OK;
 }
 int ptr_bvh_info(PtrContext *ctx, int64_t *n_nodes, int64_t *n_items, int64_t *bytes) {

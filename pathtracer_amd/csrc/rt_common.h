@@ -100,8 +100,6 @@ __device__ __forceinline__ void queue_append(int *counter, int *queue, bool pred
     }
 }
 
-/* bits k_shade leaves in hprim[slot] for k_route (ptr_runtime.hip); bit q feeds queue q = counts[q] */
-enum { ROUTE_NEXT = 1, ROUTE_NEE = 2, ROUTE_SHADOW = 4, ROUTE_MIS = 8 };
 
 enum { C_TOTAL = 0, C_MISS, C_SURF, C_MED, C_LIGHT, C_ZERO, C_SHADOW, C_MIS, C_PROBE, C_CAMERA, C_NODES, C_PRIMS, C_COUNT };
 /* pipeline statistics kept in the same lines, behind the PtrCounters fields (ptr_pipeline_stats_read) */
@@ -138,6 +136,15 @@ static inline void ensure_max_dynamic_lds(DynLdsOnce &st, const void *kernel, in
     else fprintf(stderr, "pathtracer_amd: hipFuncSetAttribute(MaxDynamicSharedMemorySize, %d) on device %d: %s\n", bytes, dev, hipGetErrorString(e));
 }
 
+/* the probe-chain records of a lane (dev_bssrdf.h, rt_shade.h): planes == null when the pass runs without them */
+struct SssChains {
+    uint32_t *planes; /* SSS_WORDS tiled planes, `cap` records */
+    int cap;
+    int *n_chains;    /* device counter of the bounce: deferred vertices numbered so far (may exceed cap) */
+    int *n_live0;     /* ... and how many of them got a record: chains 0 .. n_live0-1 enter the first round */
+    ExitNee exit;     /* direct light at the exit points as records of the tracer's launches (dev_bssrdf.h), or {null, null} */
+};
+
 /* ---- launchers (one per kernel translation unit) ---- */
 struct ShadeArgs {
     DScene sc;
@@ -146,7 +153,7 @@ struct ShadeArgs {
     const int *n_ptr;
     int n_host;
     const int *queue;
-    int *q_next, *q_nee, *q_shadow, *q_mis, *counts;
+    SssChains chains;
     int walk;
     int max_lobes; /* SSS kernel only: lobes of LDS per vertex (the scene's maximum), see rt_shade.h */
     unsigned long long *ctrs;
@@ -165,6 +172,11 @@ struct FinishArgs {
 void rt_launch_shade(unsigned blocks, hipStream_t s, const ShadeArgs &a);      /* rt_shade.hip */
 void rt_launch_shade_sss(unsigned blocks, hipStream_t s, const ShadeArgs &a);  /* rt_shade_sss.hip */
 void rt_launch_shade_defer(unsigned blocks, hipStream_t s, const ShadeArgs &a); /* rt_shade_defer.hip */
+void rt_launch_shade_begin(unsigned blocks, hipStream_t s, const ShadeArgs &a); /* rt_shade_defer.hip */
+void rt_launch_shade_tail(unsigned blocks, hipStream_t s, const ShadeArgs &a);  /* rt_shade_tail.hip */
+/* one round of the probe chains: every live chain one hit further, the survivors compacted into live_out (rt_walk.hip) */
+void rt_launch_sss_advance(unsigned blocks, hipStream_t s, const DScene &sc, const SssChains &ch, const int *n_ptr, const int *live_in, int *live_out,
+                           int *n_out, unsigned long long *ctrs);
 void rt_launch_finish(unsigned blocks, hipStream_t s, const FinishArgs &a);     /* rt_finish.hip */
 void rt_launch_finish_sss(unsigned blocks, hipStream_t s, const FinishArgs &a); /* rt_finish_sss.hip */
 void rt_launch_shadow_walk(unsigned blocks, hipStream_t s, const DScene &sc, const Pipe &pp, const int *n_ptr, int n_host, const int *queue,

@@ -24,9 +24,77 @@
  * occupancy: its lobe array is dynamic LDS sized by the scene's widest material (max_lobes x 16 KB instead of 80 KB),
  * which with the 24 KB traversal stack and the 4 KB list lets two blocks share a CU when no material pushes more than
  * three lobes. */
+/* Round 3: between the two launches the probe chains of the deferred vertices run as rays of the persistent tracer
+ * (dev_bssrdf.h "the probe chain as queued rays"):
+ *
+ *   k_shade<SSS_BEGIN>    the deferred vertices again, up to the probe segment: numbers them (one atomic per 1024 queue
+ *                         entries), leaves chain record j with its first segment, and j in the vertex's (unused) tA word;
+ *   R rounds of           k_ptrace<closest> over the live chains' segments, k_sss_advance: make_si, count / keep, next segment;
+ *   k_shade<SSS_TAIL>     the tail of every vertex whose chain is settled (finished, no more hits than the record keeps): reads
+ *                         the outcome instead of walking, leaves the exit point's direct light as a second record for the
+ *                         bounce's shadow / MIS launches (dev_bssrdf.h ExitNee).  No traversal code, no stack in LDS;
+ *   k_shade<SSS_INPLACE>  what is still deferred - a chain the rounds did not finish or with more hits than a record keeps,
+ *                         a vertex beyond the record capacity - walked in place as before.
+ * The chain's traversals - most of what the tail kernel used to spend its time on, at 3 waves/SIMD - run at the tracer's
+ * occupancy, and a vertex's traversal count no longer serialises inside one lane. */
 extern __shared__ float s_dyn_lobes[];
 #define SHADE_DEFERRED (1 << 30) /* in the hit word of a vertex k_shade<SSS_DEFER> left to the tail kernel */
 #define SSS_CHUNK 1024
+
+/* where the chain number of a deferred vertex waits for the tail kernels: the tA word of its direct-light record, which only
+ * the tracer's shadow launch writes, later in the bounce */
+#define SSS_CHAIN_WORD WORD_OF(NeeRec, tA)
+/* A deferred vertex's hit word: the primitive (scenes hold far fewer than 2^24), SHADE_DEFERRED, and in bits 24..27 the route
+ * bits of its own direct-light record, which k_shade<SSS_DEFER> has already written */
+#define SHADE_PRIM_MASK 0x00FFFFFF
+#define SHADE_ROUTE_SHIFT 24
+
+/* The deferred vertices from where k_shade<SSS_DEFER> left them (dev_path.h sss_continue), MODE = SSS_BEGIN / SSS_TAIL /
+ * SSS_INPLACE.  Returns false if the vertex is not this launch's (SSS_TAIL: its chain is not settled). */
+template <int MODE>
+__device__ __forceinline__ bool tail_slot(const DScene &sc, const Pipe &pp, const PassParams &prm, int slot, float *lobes, VertexCtr &ctr, SssCtx &sss) {
+    const int cap = pp.cap;
+    const int word = pp.hprim[slot];
+    const int hit_prim = word & SHADE_PRIM_MASK, own_route = (word >> SHADE_ROUTE_SHIFT) & (ROUTE_NEE | ROUTE_SHADOW | ROUTE_MIS);
+    PathRec ps;
+    soa_load<0, PATH_WORDS>(pp.paths, cap, slot, &ps);
+    f3 ro(pp.ro[slot], pp.ro[cap + slot], pp.ro[2 * cap + slot]);
+    f3 rd(pp.rd[slot], pp.rd[cap + slot], pp.rd[2 * cap + slot]);
+    Rng rng = make_rng(prm.seed, (uint32_t)pass_pixel(prm, slot), (uint32_t)(prm.sample_first + (slot / prm.npix) * prm.sample_step));
+    rng.dim = (uint32_t)ps.dim;
+    f3 beta = ld3(ps.beta);
+    int med = ps.medium, bounces = ps.bounces, pflags = ps.flags;
+    sss.slot = slot;
+    const TailOut to = sss_continue<MODE>(sc, prm.integrator, rng, ro, rd, med, hit_prim, pp.hface[slot], pp.ht[slot], beta, bounces, pflags, ctr, &sss, lobes);
+    if (MODE == SSS_BEGIN) return true;
+    if (!to.settled) return false;
+    if (to.has_extra) { /* direct light at the exit point, resolved in this lane: it follows the vertex's own term in L */
+        if (own_route & ROUTE_NEE) {
+            uint32_t *fw = pp.nee + plane_at(NEE_WORDS, slot, NEE_W(flags));
+            *fw |= NEE_EXTRA;
+            float *ex = reinterpret_cast<float *>(pp.nee);
+            ex[plane_at(NEE_WORDS, slot, NEE_W(extra))] = to.L_extra.x;
+            ex[plane_at(NEE_WORDS, slot, NEE_W(extra) + 1)] = to.L_extra.y;
+            ex[plane_at(NEE_WORDS, slot, NEE_W(extra) + 2)] = to.L_extra.z;
+        } else {
+            f3 L = ld3(ps.L);
+            L += to.L_extra;
+            st3(ps.L, L);
+        }
+    }
+    st3(ps.beta, beta);
+    ps.medium = med;
+    ps.bounces = bounces;
+    ps.flags = pflags;
+    ps.dim = (int)rng.dim;
+    soa_store<0, WORD_OF(PathRec, weight)>(pp.paths, cap, slot, &ps);
+    if (to.alive) {
+        pp.ro[slot] = ro.x; pp.ro[cap + slot] = ro.y; pp.ro[2 * cap + slot] = ro.z;
+        pp.rd[slot] = rd.x; pp.rd[cap + slot] = rd.y; pp.rd[2 * cap + slot] = rd.z;
+    }
+    pp.hprim[slot] = (to.alive ? ROUTE_NEXT : 0) | own_route;
+    return true;
+}
 
 template <int MODE>
 __device__ __forceinline__ void shade_slot(const DScene &sc, const Pipe &pp, const PassParams &prm, int slot, int hit_prim, float *lobes, VertexCtr &ctr,
@@ -47,25 +115,25 @@ __device__ __forceinline__ void shade_slot(const DScene &sc, const Pipe &pp, con
     rng.dim = (uint32_t)ps.dim;
     f3 L = ld3(ps.L), beta = ld3(ps.beta);
     int med = ps.medium, bounces = ps.bounces, pflags = ps.flags;
-    const VertexCtr ctr_before = ctr;
     SH_T(rec.st, SH_LOAD);
     VertexOut vo = shade_vertex<MODE>(sc, prm.integrator, rng, ro, rd, med, hit_prim, pp.hface[slot], pp.ht[slot], L, beta, bounces, pflags, rec, ctr, &sss,
                                       lobes);
     SH_T(rec.st, SH_TAIL);
-    if (MODE == SSS_DEFER && vo.defer) { /* as if this launch had never seen the vertex */
-        ctr = ctr_before;
-        pp.hprim[slot] = hit_prim | SHADE_DEFERRED;
-        return;
-    }
     const bool alive = vo.alive, want_nee = vo.want_nee;
     shaded++;
     nee_recs += want_nee ? 1 : 0;
     const bool want_shadow = want_nee && (vo.nee_flags & NEE_A), want_mis = want_nee && (vo.nee_flags & NEE_B);
-    if (MODE == SSS_INPLACE && vo.has_extra) {
-        if (want_nee) { /* keeps its place in L: after this vertex's own direct-light term */
-            rec.puti(NEE_W(flags), vo.nee_flags | NEE_EXTRA);
-            rec.put3(NEE_W(extra), vo.L_extra);
-        } else L += vo.L_extra;
+    if (MODE == SSS_DEFER && vo.defer) {
+        /* The vertex sampled the transmission of a BSSRDF material: its own part is complete and is kept - L, beta with this
+         * bounce's factor, the flags, the RNG position, the direct-light record - while the incoming ray, its medium, the bounce
+         * count and the hit stay as they are for the tail kernels, which continue from here (sss_continue). */
+        st3(ps.L, L);
+        st3(ps.beta, beta);
+        ps.flags = pflags;
+        ps.dim = (int)rng.dim;
+        soa_store<0, WORD_OF(PathRec, weight)>(pp.paths, cap, slot, &ps);
+        pp.hprim[slot] = hit_prim | SHADE_DEFERRED | (((want_nee ? ROUTE_NEE : 0) | (want_shadow ? ROUTE_SHADOW : 0) | (want_mis ? ROUTE_MIS : 0)) << SHADE_ROUTE_SHIFT);
+        return;
     }
     st3(ps.L, L);
     st3(ps.beta, beta);
@@ -86,20 +154,20 @@ __device__ __forceinline__ void shade_slot(const DScene &sc, const Pipe &pp, con
 template <int MODE>
 __global__ void __launch_bounds__(TPB)
     __attribute__((amdgpu_waves_per_eu(MODE == SSS_INPLACE ? SSS_WAVES : SHADE_WAVES, MODE == SSS_INPLACE ? SSS_WAVES : SHADE_WAVES)))
-    k_shade(DScene sc, Pipe pp, PassParams prm, const int *n_ptr, int n_host, const int *queue, int *q_next, int *q_nee, int *q_shadow, int *q_mis,
-            int *counts, int walk, unsigned long long *ctrs) {
-    constexpr bool TAIL = MODE == SSS_INPLACE;
-    __shared__ int s_stack[TAIL ? LDS_STACK * TRACE_TPB : 1];
+    k_shade(DScene sc, Pipe pp, PassParams prm, const int *n_ptr, int n_host, const int *queue, SssChains chains, int walk, unsigned long long *ctrs) {
+    constexpr bool BEGIN = MODE == SSS_BEGIN;
+    constexpr bool TAIL = MODE == SSS_INPLACE || MODE == SSS_TAIL || BEGIN; /* works on the deferred vertices of the queue, compacted per 1024 entries */
+    __shared__ int s_stack[MODE == SSS_INPLACE ? LDS_STACK * TRACE_TPB : 1];
     __shared__ float s_lobes_static[TAIL ? 1 : LOBE_LDS_WORDS]; /* 80 KB: the BSDF lobes of the block's 256 vertices (dev_bsdf.h) */
     __shared__ int s_list[TAIL ? SSS_CHUNK : 1];
-    __shared__ int s_count;
+    __shared__ int s_count, s_base;
     float *s_lobes = TAIL ? s_dyn_lobes : s_lobes_static;
     LaneStack ls;
-    ls.lds = &s_stack[TAIL ? threadIdx.x : 0];
+    ls.lds = &s_stack[MODE == SSS_INPLACE ? threadIdx.x : 0];
     NeeCtr nctr;
     nctr.shadow = nctr.mis = nctr.zero = 0;
     unsigned probes = 0;
-    const SssCtx sss = {&ls, &nctr, &probes, walk != 0};
+    SssCtx sss = {&ls, &nctr, &probes, walk != 0, ChainRef{nullptr, -1}, 0, chains.exit};
     VertexCtr ctr;
     ctr.total = ctr.miss = ctr.surf = ctr.med = ctr.light = ctr.zero = 0;
     unsigned shaded = 0, nee_recs = 0;
@@ -118,9 +186,29 @@ __global__ void __launch_bounds__(TPB)
             }
             __syncthreads();
             const int cnt = s_count;
+            if (BEGIN) { /* number the chains of this chunk: one atomic per 1024 queue entries */
+                if (threadIdx.x == 0 && cnt > 0) {
+                    s_base = atomicAdd(chains.n_chains, cnt);
+                    const int got = chains.cap - s_base < cnt ? chains.cap - s_base : cnt;
+                    if (got > 0) atomicAdd(chains.n_live0, got);
+                }
+                __syncthreads();
+            }
             for (int j = threadIdx.x; j < cnt; j += TPB) {
                 const int slot = s_list[j];
-                shade_slot<MODE>(sc, pp, prm, slot, pp.hprim[slot] & ~SHADE_DEFERRED, &s_lobes[threadIdx.x], ctr, sss, shaded, nee_recs SH_STATS_ARG);
+                if (BEGIN) {
+                    const int cj = s_base + j;
+                    const bool has = cj < chains.cap;
+                    pp.nee[plane_at(NEE_WORDS, slot, SSS_CHAIN_WORD)] = (uint32_t)(has ? cj : -1);
+                    if (has) {
+                        if (chains.exit.route) chains.exit.route[cj] = 0; /* no exit-point record yet */
+                        sss.chain = ChainRef{chains.planes, cj};
+                        tail_slot<SSS_BEGIN>(sc, pp, prm, slot, &s_lobes[threadIdx.x], ctr, sss);
+                    }
+                } else {
+                    sss.chain = ChainRef{chains.planes, chains.planes ? (int)pp.nee[plane_at(NEE_WORDS, slot, SSS_CHAIN_WORD)] : -1};
+                    tail_slot<MODE == SSS_TAIL ? SSS_TAIL : SSS_INPLACE>(sc, pp, prm, slot, &s_lobes[threadIdx.x], ctr, sss);
+                }
             }
             __syncthreads();
         }
@@ -143,6 +231,7 @@ __global__ void __launch_bounds__(TPB)
     if (__lane_id() == 0)
         for (int k = 0; k < SH_N; k++) atomicAdd(&g_sh_stats[k], shs_.acc[k]);
 #endif
+    if (BEGIN) return; /* nothing of the replay is counted */
     ctr_flush(ctrs, C_TOTAL, ctr.total);
     ctr_flush(ctrs, C_MISS, ctr.miss);
     ctr_flush(ctrs, C_SURF, ctr.surf);
@@ -151,7 +240,7 @@ __global__ void __launch_bounds__(TPB)
     ctr_flush(ctrs, C_ZERO, ctr.zero);
     ctr_flush(ctrs, CX_SHADED, shaded);
     ctr_flush(ctrs, CX_NEE_RECORDS, nee_recs);
-    if (TAIL) {
+    if (MODE == SSS_INPLACE) {
         ctr_flush(ctrs, C_SHADOW, nctr.shadow);
         ctr_flush(ctrs, C_MIS, nctr.mis);
         ctr_flush(ctrs, C_PROBE, probes);
@@ -160,12 +249,11 @@ __global__ void __launch_bounds__(TPB)
 
 template <int MODE> static void rt_launch_shade_t(unsigned blocks, hipStream_t s, const ShadeArgs &a) {
     size_t dyn = 0;
-    if (MODE == SSS_INPLACE) {
+    if (MODE == SSS_INPLACE || MODE == SSS_BEGIN || MODE == SSS_TAIL) {
         int lobes = a.max_lobes < 1 ? 1 : (a.max_lobes > MAX_LOBES ? MAX_LOBES : a.max_lobes);
         dyn = (size_t)lobes * LOBE_WORDS * LOBE_STRIDE * sizeof(float);
         static DynLdsOnce once;
         ensure_max_dynamic_lds(once, reinterpret_cast<const void *>(&k_shade<MODE>), (int)(MAX_LOBES * LOBE_WORDS * LOBE_STRIDE * sizeof(float)));
     }
-    hipLaunchKernelGGL(k_shade<MODE>, dim3(blocks), dim3(TPB), dyn, s, a.sc, a.pp, a.prm, a.n_ptr, a.n_host, a.queue, a.q_next, a.q_nee, a.q_shadow,
-                       a.q_mis, a.counts, a.walk, a.ctrs);
+    hipLaunchKernelGGL(k_shade<MODE>, dim3(blocks), dim3(TPB), dyn, s, a.sc, a.pp, a.prm, a.n_ptr, a.n_host, a.queue, a.chains, a.walk, a.ctrs);
 }
