@@ -303,18 +303,19 @@ PD int bssrdf_probe_chain(const DScene &sc, const f3 &start, const f3 &pTarget, 
     return nFound;
 }
 
-/* ---- the probe chain as queued rays of the persistent tracer (round 3) --------------------------------------------
- * In a staged bounce the chain is not walked in the vertex's lane: k_shade<SSS_BEGIN> replays a deferred vertex up to the
- * probe segment and leaves a CHAIN RECORD, rounds of { persistent tracer over the live chains' current segments,
- * k_sss_advance } take every chain one hit further (make_si, count / keep, next segment - the body of the loop above, one
- * iteration per round), and the tail kernel reads the outcome.  A record is SSS_WORDS 32-bit words in tiled planes
- * (dev_nee.h plane_at) indexed by the chain's number, so that the tracer fetches the segment and stores the hit in place. */
+/* ---- the probe chain as rays of the persistent tracer (round 3) ------------------------------------------------------
+ * In a staged bounce the chain is not walked in the vertex's lane: k_shade<SSS_BEGIN> sets the probe of a deferred vertex up and
+ * leaves a CHAIN RECORD; k_pchain, the persistent tracer with a source that CONTINUES (dev_trace.h ChainSource), traces the
+ * chain's current segment and, when a batch of its lanes have an answer, takes each of those chains one hit further
+ * (chain_advance: make_si, count / keep, next segment - the body of the loop above) and traces on in the same lane until the
+ * chain ends; the tail kernel reads the outcome.  A record is SSS_WORDS 32-bit words in tiled planes (dev_nee.h plane_at)
+ * indexed by the chain's number. */
 enum {
     SW_O = 0,        /* current segment: origin (3), direction (3) - what the tracer reads */
     SW_D = 3,
-    SW_HIT = 6,      /* tracer result: primitive or -1, */
-    SW_T = 7,        /* distance (1 - ShadowEpsilon on a miss), */
-    SW_FACE = 8,     /* face */
+    SW_HIT = 6,      /* (unused since the chains are advanced inside the tracer: three spare words) */
+    SW_T = 7,
+    SW_FACE = 8,
     SW_TARGET = 9,   /* pTarget (3) */
     SW_SLOT = 12,    /* path slot of the vertex */
     SW_STATE = 13,   /* SSS_LIVE while segments remain, then SSS_DONE */
@@ -361,15 +362,15 @@ PD void chain_begin(const ChainRef &c, int slot, int prim, const f3 &start, cons
     c.puti(SW_MED, si_medium(f3(0.f), -1, -1, d));
     c.puti(SW_PRIM, prim);
 }
-/* one iteration of the loop above for a chain whose current segment the tracer has just answered; false: the chain has ended */
-PD bool chain_advance(const DScene &sc, const ChainRef &c) {
+/* one iteration of the loop above for a chain whose current segment has just been traced (hp < 0: nothing hit; t: where the
+ * segment ended); false: the chain has ended.  The next segment is left in the record and returned in *o_next / *d_next. */
+PD bool chain_advance(const DScene &sc, const ChainRef &c, int hp, int hf, float t, f3 *o_next, f3 *d_next) {
     const f3 o = c.get3(SW_O), d = c.get3(SW_D);
-    const int hp = c.geti(SW_HIT), steps = c.geti(SW_STEPS) + 1;
+    const int steps = c.geti(SW_STEPS) + 1;
     c.puti(SW_STEPS, steps);
     bool live = !(is_black(d) || hp < 0) && steps < PROBE_MAX_STEPS;
     if (live) {
-        const float t = c.getf(SW_T);
-        const int hf = c.geti(SW_FACE), med = c.geti(SW_MED);
+        const int med = c.geti(SW_MED);
         SI si;
         make_si(sc, hp, hf, o, d, t, med, &si);
         if (hp == c.geti(SW_PRIM)) {
@@ -383,9 +384,12 @@ PD bool chain_advance(const DScene &sc, const ChainRef &c) {
         }
         if (live) {
             const f3 dn = c.get3(SW_TARGET) - si.p;
-            c.put3(SW_O, offset_ray_origin(si.p, si.pError, si.n, dn));
+            const f3 on = offset_ray_origin(si.p, si.pError, si.n, dn);
+            c.put3(SW_O, on);
             c.put3(SW_D, dn);
             c.puti(SW_MED, si_medium(si.n, si.med_in, si.med_out, dn));
+            *o_next = on;
+            *d_next = dn;
         }
     }
     if (!live) c.puti(SW_STATE, SSS_DONE);
@@ -486,10 +490,8 @@ PD f3 bssrdf_exit_point(const DScene &sc, const ProbeSetup &ps, const ChainRef &
                 int hp = -1, hf = 0;
                 if (probes) (*probes)++;
                 const bool hit = traverse<false, false>(sc, chain.get3(SW_O), chain.get3(SW_D), tmax, hp, hf, b0, b1, nullptr, ls);
-                chain.puti(SW_HIT, hit ? hp : -1);
-                chain.putf(SW_T, tmax);
-                chain.puti(SW_FACE, hit ? hf : -1);
-                chain_advance(sc, chain);
+                f3 on, dn;
+                chain_advance(sc, chain, hit ? hp : -1, hf, tmax, &on, &dn);
             }
         }
         nFound = chain.geti(SW_FOUND);

@@ -38,7 +38,7 @@ struct TraceIO {
     int w_face1;    /* tiled planes, closest hit: 1 + the word that receives the face (0: the face is not stored) */
 };
 
-enum { TM_IDLE = 0, TM_TOP = 1, TM_TOPLEAF = 2, TM_GEOM = 3 };
+enum { TM_IDLE = 0, TM_TOP = 1, TM_TOPLEAF = 2, TM_GEOM = 3, TM_DONE = 4 /* CONTINUES sources: the ray has its answer and waits for src.advance */ };
 
 #define PT_PUSH(v)                                          \
     do {                                                    \
@@ -115,6 +115,7 @@ PD void trace_io_store(const TraceIO &io, bool any, int slot, bool hit, int hp, 
  * and run their last waves on a mostly empty GPU. */
 template <bool ANY>
 struct OneSource {
+    static constexpr bool CONTINUES = false;
     TraceIO io;
     int n_rays;
     int *counter;
@@ -128,6 +129,7 @@ struct OneSource {
     }
 };
 struct ThreeSources {
+    static constexpr bool CONTINUES = false;
     TraceIO path, shadow, mis; /* path.counter is the fetch cursor of the launch */
     int n0, n01, n012;
     int *counter;
@@ -154,6 +156,7 @@ struct ThreeSources {
 
 /* Two any-hit queues in one launch: the shadow rays and - where any hit answers them (ptr_runtime.hip) - the MIS rays of a bounce */
 struct TwoAny {
+    static constexpr bool CONTINUES = false;
     TraceIO a, b; /* a.counter is the fetch cursor of the launch */
     int n0, n01;
     int *counter;
@@ -172,6 +175,40 @@ struct TwoAny {
     PD void store(int tag, int slot, bool hit, int hp, int hf, float tmax, float hb0, float hb1, unsigned rn, unsigned ri) const {
         if (tag == 0) trace_io_store<COUNT>(a, true, slot, hit, hp, hf, tmax, hb0, hb1, rn, ri);
         else trace_io_store<COUNT>(b, true, slot, hit, hp, hf, tmax, hb0, hb1, rn, ri);
+    }
+};
+
+/* A source whose rays CONTINUE: when a ray has its answer the lane does not take the next ray of the queue but waits (TM_DONE)
+ * until a batch of lanes can run src.advance together - the per-ray work between two dependent scene queries - and then
+ * traces the follow-up ray advance hands back, until it says the chain has ended.  A chain of dependent queries thus runs
+ * to its end at the tracer's occupancy, in one launch, however long it is.
+ * ChainSource: the BSSRDF probe chains (dev_bssrdf.h): ray = the chain's current segment, advance = chain_advance. */
+struct ChainSource {
+    static constexpr bool CONTINUES = true;
+    uint32_t *planes;
+    const int *n_ptr;
+    int n_rays;
+    int *counter;
+    unsigned *probes; /* the kernel's per-lane count of probe rays */
+    PD void init() { n_rays = *n_ptr; }
+    PD int total() const { return n_rays; }
+    PD bool is_any(int) const { return false; }
+    PD void fetch(int idx, int *tag, int *slot, f3 *ro, f3 *rd, float *tmax) const {
+        const ChainRef c = {planes, idx};
+        *tag = 0;
+        *slot = idx;
+        *ro = c.get3(SW_O); /* a chain that was finished when it was made has a null segment: the ray ends at once, advance declines */
+        *rd = c.get3(SW_D);
+        *tmax = 1 - kShadowEpsilon; /* Interaction::SpawnRayTo(Point3f), interaction.cpp:12-16 */
+    }
+    template <bool COUNT>
+    PD void store(int, int, bool, int, int, float, float, float, unsigned, unsigned) const {}
+    PD bool advance(const DScene &sc, int, int slot, bool hit, int hp, int hf, float t, f3 *ro, f3 *rd, float *tmax) {
+        const ChainRef c = {planes, slot};
+        if (c.geti(SW_STATE) != SSS_LIVE) return false;
+        (*probes)++; /* the segment just traced: one probe ray (bssrdf.cpp:536) */
+        *tmax = 1 - kShadowEpsilon;
+        return chain_advance(sc, c, hit ? hp : -1, hf, t, ro, rd);
     }
 };
 
@@ -229,16 +266,40 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *s
 
 #define PT_FINISH()                                                                  \
     do {                                                                             \
-        src.template store<COUNT>(tag, slot, hit, hp, hf, tmax, hb0, hb1, rn, ri);   \
         if (COUNT) { *total_nodes += rn; *total_items += ri; }                       \
-        mode = TM_IDLE;                                                              \
-        slot = -1;                                                                   \
+        if (Source::CONTINUES) mode = TM_DONE;                                       \
+        else {                                                                       \
+            src.template store<COUNT>(tag, slot, hit, hp, hf, tmax, hb0, hb1, rn, ri); \
+            mode = TM_IDLE;                                                          \
+            slot = -1;                                                               \
+        }                                                                            \
     } while (0)
 #define PT_ANY (src.is_any(tag))
 
     for (;;) {
         PS_ADD(PS_OUTER, 1);
         const long long c0_ = PS_CLOCK();
+        /* ---- CONTINUES sources: the rays that have their answer, in batches like the refill below ---- */
+        if constexpr (Source::CONTINUES) {
+            const unsigned long long done = __ballot(mode == TM_DONE);
+            if (done && (__popcll(done) >= PT_REFILL || __ballot(mode == TM_GEOM) == 0)) {
+                if (mode == TM_DONE) {
+                    if (src.advance(sc, tag, slot, hit, hp, hf, tmax, &ro, &rd, &tmax)) {
+                        inv = f3(1 / rd.x, 1 / rd.y, 1 / rd.z);
+                        tr = tri_ray_setup(rd);
+                        hp = -1; hf = -1; hb0 = 0; hb1 = 0; hit = false;
+                        rn = 0; ri = 0;
+                        sp = 0;
+                        PT_PUSH(-1);
+                        tnode = sc.n_top == 0 ? -1 : 0; /* (an empty scene: the walk ends at its first step) */
+                        mode = TM_TOP;
+                    } else {
+                        mode = TM_IDLE;
+                        slot = -1;
+                    }
+                }
+            }
+        }
         /* ---- refill idle lanes ---- */
         unsigned long long idle = __ballot(mode == TM_IDLE);
         /* refill in batches: the top-level phase a new ray starts with (analytic primitives: a

@@ -414,12 +414,11 @@ struct ProfSpan {
 #define N_LANES 6 /* passes in flight (each on its own stream, ~5 GB of buffers at 16 M slots): 4 -> 6 gave +3.5 %, 8 no more */
 #define MAX_ITERS 20
 #define LANE_COUNTER_INTS (10 * MAX_ITERS)
-/* BSSRDF probe chains as tracer rays (rt_shade.h): rounds per bounce, and the lane's counters for them - per bounce
- * [0] deferred vertices, [1] chains entering round 0, [2 + r] chains entering round r + 1, [2 + SSS_ROUNDS_MAX + r] the
- * ray-fetch cursor of round r's tracer launch */
-#define SSS_ROUNDS_MAX 12
-#define SSS_EXIT_COUNTS (2 + 2 * SSS_ROUNDS_MAX) /* [0..4): k_route's counters over the exit-point records (unused, records, shadow rays, MIS rays); [4], [5]: fetch cursors */
-#define SSS_COUNTER_STRIDE (SSS_EXIT_COUNTS + 6)
+/* BSSRDF probe chains as tracer rays (rt_shade.h): the lane's counters for them, per staged bounce: [0] deferred vertices,
+ * [1] chains that got a record, [2] the ray-fetch cursor of the chain launch, [4..8) k_route's counters over the exit-point
+ * records (unused, records, shadow rays, MIS rays), [8], [9] the fetch cursors of their rays */
+#define SSS_EXIT_COUNTS 4
+#define SSS_COUNTER_STRIDE 16
 #define SSS_COUNTER_INTS (SSS_COUNTER_STRIDE * MAX_ITERS)
 struct Lane {
     hipStream_t stream = nullptr;
@@ -432,7 +431,6 @@ struct Lane {
     int staged_used = 0, slots_used = 0; /* of the pass last queued on this lane */
     /* probe-chain records (scenes with a BSSRDF material only; allocated at the first such pass) */
     uint32_t *sss_planes = nullptr;
-    int *sss_live[2] = {nullptr, nullptr};
     int *sss_counts = nullptr;
     int sss_cap = 0;
     /* direct light at the exit points as records of their own (dev_bssrdf.h ExitNee): planes, flags per chain, the three queues */
@@ -441,10 +439,9 @@ struct Lane {
 };
 
 static void lane_free_sss(Lane &l) {
-    for (void *p : {(void *)l.sss_planes, (void *)l.sss_live[0], (void *)l.sss_live[1], (void *)l.sss_counts, (void *)l.sss_nee2, (void *)l.sss_route,
-                    (void *)l.sss_q[0], (void *)l.sss_q[1], (void *)l.sss_q[2]})
+    for (void *p : {(void *)l.sss_planes, (void *)l.sss_counts, (void *)l.sss_nee2, (void *)l.sss_route, (void *)l.sss_q[0], (void *)l.sss_q[1], (void *)l.sss_q[2]})
         if (p) (void)hipFree(p);
-    l.sss_planes = nullptr; l.sss_live[0] = l.sss_live[1] = nullptr; l.sss_counts = nullptr;
+    l.sss_planes = nullptr; l.sss_counts = nullptr;
     l.sss_nee2 = nullptr; l.sss_route = nullptr; l.sss_q[0] = l.sss_q[1] = l.sss_q[2] = nullptr;
 }
 
@@ -464,7 +461,7 @@ struct PtrContext {
     bool mis_any_hit = true; /* MIS rays as any-hit rays where the result cannot tell the difference (PTR_MIS_ANY=0: never) */
     int scene_max_lobes = MAX_LOBES;
     bool scene_has_sss = false; /* some material carries a BSSRDF: k_shade<true> / k_finish<true> */
-    int sss_rounds = 4;         /* tracer rounds per bounce for the probe chains (PTR_SSS_ROUNDS; 0: chains are walked in the tail kernel as in round 2) */
+    int sss_rounds = 1;         /* probe chains as rays of the continuing tracer (PTR_SSS_CHAINS=0: walked in the tail kernel's lanes as in round 2) */
     int sss_cap_div = 4;        /* chain records per lane = path slots / this (PTR_SSS_CAP_DIV) */
     bool sss_exit_records = true; /* direct light at the exit points through the tracer's launches (PTR_SSS_EXIT=0: resolved in the tail kernel) */
     /* Which persistent tracer a launch uses.  One ray per lane (dev_trace.h) has the higher throughput once the GPU is full
@@ -679,9 +676,6 @@ static TraceIO mis_io(const Lane &l, const int *queue, const int *n_ptr, int *cu
     io.counter = cursor;
     return io;
 }
-/* The probe chains of the bounce's deferred vertices as rays of the persistent tracer (rt_shade.h, dev_bssrdf.h): the begin
- * kernel numbers the chains and leaves their first segments, then sss_rounds times { tracer over the live chains, advance }.
- * a.chains is filled in for the tail kernel that follows.  The lane's SSS counters must be zero (run_pass). */
 /* Direct light at the exit points as records of the tracer's launches?  Not where its rays may pass through primitives (the
  * in-kernel walks: Li_VolPath in a scene that is not all opaque), nor with the merged three-kind launch (PTR_MERGE). */
 static bool exit_records(const PtrContext *ctx, const Lane &l, int integrator) {
@@ -701,26 +695,17 @@ static TraceIO exit_io(const Lane &l, int cslot, bool mis) {
     io.counter = cnt2 + (mis ? 5 : 4);
     return io;
 }
+/* The probe chains of the bounce's deferred vertices as rays of the persistent tracer (rt_shade.h, dev_bssrdf.h): the begin
+ * kernel numbers the chains and leaves their first segments, one launch of the continuing tracer runs every chain to its end.
+ * a.chains is filled in for the tail kernels that follow.  The lane's SSS counters must be zero (run_pass). */
 static void enqueue_probe_chains(PtrContext *ctx, Lane &l, ShadeArgs &a, int n_upper, int cslot, unsigned tail_blocks) {
     hipStream_t s = l.stream;
     int *cnt = l.sss_counts + SSS_COUNTER_STRIDE * cslot;
     a.chains = SssChains{l.sss_planes, l.sss_cap, cnt + 0, cnt + 1, ExitNee{exit_records(ctx, l, a.prm.integrator) ? l.sss_nee2 : nullptr, l.sss_route}};
     rt_launch_shade_begin(tail_blocks, s, a);
     const int upper = n_upper < l.sss_cap ? n_upper : l.sss_cap;
-    for (int r = 0; r < ctx->sss_rounds; r++) {
-        const int *n_ptr = cnt + 1 + r;
-        const int *live_in = r == 0 ? nullptr : l.sss_live[(r - 1) & 1];
-        TraceIO io;
-        memset(&io, 0, sizeof(io));
-        io.queue = live_in; io.n_ptr = n_ptr;
-        io.tile_words = SSS_WORDS;
-        io.o = (const char *)l.sss_planes; io.w_o = SW_O; io.w_d = SW_D;
-        io.tmax_const = 1 - 0.0001f; /* 1 - ShadowEpsilon: Interaction::SpawnRayTo (interaction.cpp:12-16) */
-        io.prim = (char *)l.sss_planes; io.w_prim = SW_HIT; io.w_t = SW_T; io.w_face1 = SW_FACE + 1;
-        io.counter = cnt + 2 + SSS_ROUNDS_MAX + r;
-        launch_ptrace(ctx, s, io, upper, false, false, K_PROBE);
-        rt_launch_sss_advance(clampu(nblocks(upper), 32, 2048), s, ctx->sc, a.chains, n_ptr, live_in, l.sss_live[r & 1], cnt + 2 + r, ctx->ctrs);
-    }
+    ProfScope ps(ctx, s, K_PROBE, 0);
+    rt_launch_pchain(clampu(nblocks(upper), 1, (unsigned)ctx->persist_blocks), s, ctx->sc, l.sss_planes, cnt + 1, cnt + 2, ctx->ctrs);
 }
 static void enqueue_shade(PtrContext *ctx, Lane &l, const PassParams &prm, const int *n_ptr, int n_host, int n_upper, const int *q_cur, int *q_next,
                           int cslot) {
@@ -755,7 +740,7 @@ static void enqueue_shade(PtrContext *ctx, Lane &l, const PassParams &prm, const
         int *scnt = l.sss_counts + SSS_COUNTER_STRIDE * cslot;
         const int upper = n_upper < l.sss_cap ? n_upper : l.sss_cap;
         hipLaunchKernelGGL(k_route, dim3(clampu(nblocks((upper + ROUTE_CHUNK - 1) / ROUTE_CHUNK), 32, 2048)), dim3(TPB), 0, s, (const int *)(scnt + 1),
-                           (const int *)nullptr, (const int *)l.sss_route, l.sss_live[0], l.sss_q[0], l.sss_q[1], l.sss_q[2], scnt + SSS_EXIT_COUNTS);
+                           (const int *)nullptr, (const int *)l.sss_route, l.sss_q[0] /* (bit 0 is never set) */, l.sss_q[0], l.sss_q[1], l.sss_q[2], scnt + SSS_EXIT_COUNTS);
     }
 }
 /* the exit-point records of the bounce summed into L (after enqueue_resolve: their term follows the vertex's own) */
@@ -799,6 +784,30 @@ static void enqueue_resolve(PtrContext *ctx, Lane &l, int n_upper, int cslot, bo
         if (le_ != hipSuccess) return set_err(PTR_ERR_HIP, std::string("pass stage '") + (what) + "': " + hipGetErrorString(le_)); \
     } while (0)
 
+/* Scenes with a BSSRDF material: the probe-chain and exit-point records of EVERY lane, made at the first ptr_render that needs
+ * them (one chain record per sss_cap_div path slots; vertices beyond that walk their chain in the tail kernel).  All lanes at once:
+ * an allocation of gigabytes stalls the device, and must not fall into a later call's passes.  If the memory is not there the
+ * lanes run without records, as in round 2. */
+static void ensure_sss_buffers(PtrContext *ctx) {
+    if (!ctx->scene_has_sss || ctx->sss_rounds <= 0) return;
+    for (Lane &l : ctx->lanes) {
+        if (l.sss_planes || l.sss_cap != 0 || !l.pipe.cap) continue;
+        const size_t want = ((((size_t)l.pipe.cap / ctx->sss_cap_div) >> PLANE_TILE_SHIFT) + 1) << PLANE_TILE_SHIFT;
+        hipError_t e = hipMalloc((void **)&l.sss_planes, want * SSS_WORDS * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc((void **)&l.sss_counts, SSS_COUNTER_INTS * sizeof(int));
+        if (e == hipSuccess && ctx->sss_exit_records) {
+            e = hipMalloc((void **)&l.sss_nee2, want * sizeof(NeeRec));
+            if (e == hipSuccess) e = hipMalloc((void **)&l.sss_route, want * sizeof(int));
+            for (int q = 0; q < 3 && e == hipSuccess; q++) e = hipMalloc((void **)&l.sss_q[q], want * sizeof(int));
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            lane_free_sss(l);
+            l.sss_cap = -1; /* do not try again for these pass buffers */
+        } else l.sss_cap = (int)want;
+    }
+}
+
 /* one pass on a lane: nb samples (first, first+step, ...) of every pixel */
 static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int step, int nb, int integrator) {
     PassParams prm;
@@ -837,25 +846,6 @@ static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int ste
     }
     const size_t cbytes = (size_t)LANE_COUNTER_INTS * sizeof(int);
     HIPCHK(hipMemsetAsync(l.counts, 0, cbytes, s));
-    if (ctx->scene_has_sss && ctx->sss_rounds > 0 && !l.sss_planes && l.sss_cap == 0) {
-        /* first pass of a scene with a BSSRDF material on this lane: room for one chain record per sss_cap_div path slots
-         * (vertices beyond that walk their chain in the tail kernel); if the memory is not there, every vertex does */
-        const size_t want = ((((size_t)l.pipe.cap / ctx->sss_cap_div) >> PLANE_TILE_SHIFT) + 1) << PLANE_TILE_SHIFT;
-        hipError_t e = hipMalloc((void **)&l.sss_planes, want * SSS_WORDS * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMalloc((void **)&l.sss_live[0], want * sizeof(int));
-        if (e == hipSuccess) e = hipMalloc((void **)&l.sss_live[1], want * sizeof(int));
-        if (e == hipSuccess) e = hipMalloc((void **)&l.sss_counts, SSS_COUNTER_INTS * sizeof(int));
-        if (e == hipSuccess && ctx->sss_exit_records) {
-            e = hipMalloc((void **)&l.sss_nee2, want * sizeof(NeeRec));
-            if (e == hipSuccess) e = hipMalloc((void **)&l.sss_route, want * sizeof(int));
-            for (int q = 0; q < 3 && e == hipSuccess; q++) e = hipMalloc((void **)&l.sss_q[q], want * sizeof(int));
-        }
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            lane_free_sss(l);
-            l.sss_cap = -1; /* do not try again for these pass buffers */
-        } else l.sss_cap = (int)want;
-    }
     if (l.sss_counts) HIPCHK(hipMemsetAsync(l.sss_counts, 0, SSS_COUNTER_INTS * sizeof(int), s));
     {
         ProfScope ps(ctx, s, K_RAYGEN, (uint64_t)slots);
@@ -1070,7 +1060,7 @@ int ptr_create(int device, PtrContext **out) {
     if (const char *e = getenv("PTR_STAGE_DIV")) { int v = atoi(e); if (v > 0) ctx->stage_div = v; }
     if (const char *e = getenv("PTR_MIS_ANY")) ctx->mis_any_hit = atoi(e) != 0;
     if (const char *e = getenv("PTR_NEE_CLOSEST")) ctx->nee_closest_ok = atoi(e) != 0;
-    if (const char *e = getenv("PTR_SSS_ROUNDS")) { int v = atoi(e); if (v >= 0) ctx->sss_rounds = v > SSS_ROUNDS_MAX ? SSS_ROUNDS_MAX : v; }
+    if (const char *e = getenv("PTR_SSS_CHAINS")) ctx->sss_rounds = atoi(e) != 0 ? 1 : 0;
     if (const char *e = getenv("PTR_SSS_CAP_DIV")) { int v = atoi(e); if (v >= 1) ctx->sss_cap_div = v; }
     if (const char *e = getenv("PTR_SSS_EXIT")) ctx->sss_exit_records = atoi(e) != 0;
     if (const char *e = getenv("PTR_SPREAD")) { /* tuning experiments */
@@ -1475,6 +1465,7 @@ int ptr_render(PtrContext *ctx, int ns, int integrator) {
     int first = begin + ((ctx->shard_offset - begin) % stride + stride) % stride;
     bool used[N_LANES] = {};
     if (ctx->npix_local == 0) return PTR_OK; /* a tile shard without tiles */
+    ensure_sss_buffers(ctx);
     /* samples per pass: what the pass buffers hold of this context's pixels */
     long long nb_cap = (long long)ctx->lanes[0].pipe.cap / ctx->npix_local;
     if (nb_cap > 64) nb_cap = 64;
@@ -1773,8 +1764,7 @@ int ptr_profile_read(PtrContext *ctx, PtrKernelProfile *out, int max_entries, in
     if (n_out) *n_out = n;
     return PTR_OK;
 }
-/* diagnostic (tools/gpu_sss_rounds.py): the probe-chain counters of the pass last run on lane `lane`, SSS_COUNTER_STRIDE ints
- * per staged bounce - deferred vertices, chains entering round 0, chains entering round r + 1 ... */
+/* diagnostic: the probe-chain counters of the pass last run on lane `lane`, SSS_COUNTER_STRIDE ints per staged bounce (layout above) */
 int ptr_debug_sss_counts(PtrContext *ctx, int lane, int *out, int n_ints, int *stride) {
     int rc = ctx_use(ctx);
     if (rc) return rc;

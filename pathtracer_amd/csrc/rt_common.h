@@ -174,9 +174,8 @@ void rt_launch_shade_sss(unsigned blocks, hipStream_t s, const ShadeArgs &a);  /
 void rt_launch_shade_defer(unsigned blocks, hipStream_t s, const ShadeArgs &a); /* rt_shade_defer.hip */
 void rt_launch_shade_begin(unsigned blocks, hipStream_t s, const ShadeArgs &a); /* rt_shade_defer.hip */
 void rt_launch_shade_tail(unsigned blocks, hipStream_t s, const ShadeArgs &a);  /* rt_shade_tail.hip */
-/* one round of the probe chains: every live chain one hit further, the survivors compacted into live_out (rt_walk.hip) */
-void rt_launch_sss_advance(unsigned blocks, hipStream_t s, const DScene &sc, const SssChains &ch, const int *n_ptr, const int *live_in, int *live_out,
-                           int *n_out, unsigned long long *ctrs);
+/* every probe chain of a bounce traced to its end in one launch of the continuing persistent tracer (rt_trace.hip) */
+void rt_launch_pchain(unsigned blocks, hipStream_t s, const DScene &sc, uint32_t *planes, const int *n_ptr, int *cursor, unsigned long long *ctrs);
 void rt_launch_finish(unsigned blocks, hipStream_t s, const FinishArgs &a);     /* rt_finish.hip */
 void rt_launch_finish_sss(unsigned blocks, hipStream_t s, const FinishArgs &a); /* rt_finish_sss.hip */
 void rt_launch_shadow_walk(unsigned blocks, hipStream_t s, const DScene &sc, const Pipe &pp, const int *n_ptr, int n_host, const int *queue,

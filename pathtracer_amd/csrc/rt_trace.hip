@@ -78,6 +78,30 @@ void rt_launch_ptrace2any(unsigned blocks, hipStream_t s, const DScene &sc, cons
     hipLaunchKernelGGL(k_ptrace2any, dim3(blocks), dim3(TRACE_TPB), 0, s, sc, a, b);
 }
 
+/* The BSSRDF probe chains (dev_bssrdf.h): the persistent tracer with a source that continues - every chain is traced segment by
+ * segment to its end inside this one launch (dev_trace.h ChainSource).  chain_advance builds a surface interaction per hit, so the
+ * kernel is given more registers than the plain tracer: PCHAIN_WAVES waves per SIMD. */
+#ifndef PCHAIN_WAVES
+#define PCHAIN_WAVES 4
+#endif
+__global__ void __launch_bounds__(TRACE_TPB) __attribute__((amdgpu_waves_per_eu(PCHAIN_WAVES, PCHAIN_WAVES)))
+k_pchain(DScene sc, uint32_t *planes, const int *n_ptr, int *cursor, unsigned long long *ctrs) {
+    __shared__ int s_stack[LDS_STACK * TRACE_TPB];
+    PT_STAGED_NODES(sc);
+    PT_STAGED_TOP(sc);
+    unsigned tn = 0, ti = 0, probes = 0;
+    ChainSource src;
+    src.planes = planes;
+    src.n_ptr = n_ptr;
+    src.counter = cursor;
+    src.probes = &probes;
+    persistent_trace<ChainSource, false>(sc, src, &s_stack[threadIdx.x], s_staged, s_top, &tn, &ti);
+    ctr_flush(ctrs, C_PROBE, probes);
+}
+void rt_launch_pchain(unsigned blocks, hipStream_t s, const DScene &sc, uint32_t *planes, const int *n_ptr, int *cursor, unsigned long long *ctrs) {
+    hipLaunchKernelGGL(k_pchain, dim3(blocks), dim3(TRACE_TPB), 0, s, sc, planes, n_ptr, cursor, ctrs);
+}
+
 void rt_launch_ptrace3(bool count, unsigned blocks, hipStream_t s, const DScene &sc, const TraceIO &path, const TraceIO &shadow, const TraceIO &mis,
                        unsigned long long *ctrs) {
     if (count) hipLaunchKernelGGL((k_ptrace3<true>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, path, shadow, mis, ctrs);

@@ -65,29 +65,3 @@ void rt_launch_mis_walk(unsigned blocks, hipStream_t s, const DScene &sc, const 
                         unsigned long long *ctrs) {
     hipLaunchKernelGGL(k_mis_walk, dim3(blocks), dim3(TPB), 0, s, sc, pp, n_ptr, n_host, queue, ctrs);
 }
-
-/* One round of the BSSRDF probe chains (dev_bssrdf.h): the tracer has answered the current segment of every live chain;
- * each takes the hit (make_si, count / keep on the probed primitive), sets up its next segment, and the chains that go on
- * are compacted into live_out.  live_in = null: chains 0 .. n-1 (the first round).  A streaming kernel over <= n records. */
-__global__ void __launch_bounds__(TPB) k_sss_advance(DScene sc, SssChains ch, const int *n_ptr, const int *live_in, int *live_out, int *n_out,
-                                                     unsigned long long *ctrs) {
-    unsigned probes = 0;
-    GRID_STRIDE_BEGIN(n_ptr, 0)
-    bool live = false;
-    int j = 0;
-    if (i < n) {
-        j = live_in ? live_in[i] : i;
-        const ChainRef c = {ch.planes, j};
-        if (c.geti(SW_STATE) == SSS_LIVE) {
-            probes++; /* the segment the tracer has just traced: one probe ray (bssrdf.cpp:536) */
-            live = chain_advance(sc, c);
-        }
-    }
-    queue_append(n_out, live_out, live, j);
-    GRID_STRIDE_END
-    ctr_flush(ctrs, C_PROBE, probes);
-}
-void rt_launch_sss_advance(unsigned blocks, hipStream_t s, const DScene &sc, const SssChains &ch, const int *n_ptr, const int *live_in, int *live_out,
-                           int *n_out, unsigned long long *ctrs) {
-    hipLaunchKernelGGL(k_sss_advance, dim3(blocks), dim3(TPB), 0, s, sc, ch, n_ptr, live_in, live_out, n_out, ctrs);
-}
