@@ -224,6 +224,7 @@ def main():
     step()
     r.sync()
     cc = r.counters()
+    sc_count = r.pipeline_stats()
     r.profile_enable(timing=True, count_traversal=False)
     r.profile_reset()
     r.counters_reset()
@@ -294,6 +295,27 @@ def main():
         t_launches, t_ms = closest(prof)
         t_avg_ms = t_ms / max(1, t_launches)
         traffic = measured_traffic(summary, "k_ptrace<false, false>", args.config)
+        # ---- the any-hit tracer k_ptrace<true,false> (shadow rays; MIS rays where any hit answers them): the largest kernel by
+        # exclusive time on configs[1].  Same pricing, B = 52 (48 B ray in, 4 B answer out) + 32 per child box + 48 per item, with
+        # its own per-ray counts from the counting pass (an any-hit ray ends at its first hit).
+        any_launches = (0 if shadow_closest or walks else profx["nee_shadow"]["launches"]) + profx["nee_mis_any"]["launches"]
+        any_ms = (0.0 if shadow_closest or walks else profx["nee_shadow"]["total_ms"]) + profx["nee_mis_any"]["total_ms"]
+        roofline_any = None
+        if any_launches and sc_count["any_rays"]:
+            a_nodes = sc_count["any_nodes"] / sc_count["any_rays"]
+            a_items = sc_count["any_items"] / sc_count["any_rays"]
+            a_bytes = 52.0 + 32.0 * a_nodes + 48.0 * a_items
+            kinds_any = (0 if shadow_closest or walks else 1) + (1 if mis_any else 0)  # of the two direct-light ray kinds, how many are any-hit rays
+            a_rays = ((0 if shadow_closest or walks else cx["shadow_rays"]) + (cx["mis_rays"] if mis_any else 0)
+                      - sx["finish_nee_rays"] * kinds_any / 2.0) / any_launches  # the finish kernel traces its direct-light rays itself
+            a_avg = any_ms / any_launches
+            a_ach = a_bytes * a_rays / (a_avg * 1e-3) / 1e9 if a_avg > 0 else 0.0
+            roofline_any = {"bound": "hbm", "kernel": "k_ptrace<true,false> (persistent tracer, any hit: shadow rays + MIS rays that any hit answers)",
+                            "achieved": a_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a_ach / HBM_PEAK_GBS,
+                            "traffic": measured_traffic(summary, "k_ptrace<true, false>", args.config), "traffic_unit": "bytes per launch",
+                            "bytes_per_ray": a_bytes, "nodes_per_ray": a_nodes, "items_per_ray": a_items, "avg_launch_ms": a_avg,
+                            "rays_per_launch": a_rays, "launches": any_launches,
+                            "note": "the direct-light rays the finish kernel traces inside itself are taken off (half of them per any-hit ray kind)"}
         # ---- shade stage (k_shade + k_route): SURVEY 8(d) B_shade = 192 B per shaded vertex, + the 192-B direct-light record
         # of the vertices that write one
         sh_launches = max(1, profx["shade"]["launches"])
@@ -343,6 +365,7 @@ def main():
                                      "rays the finish kernel traces inside itself are not counted",
                          "timed_region": {"avg_launch_ms": t_avg_ms, "launches": t_launches,
                                           "note": "six passes overlap on six streams: a launch shares the GPU with other passes' kernels"}},
+            "roofline_any": roofline_any,
             "roofline_shade": {"bound": "hbm", "kernel": "k_shade + k_route (one integrator iteration per path vertex, queue routing)",
                                "achieved": sh_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sh_achieved / HBM_PEAK_GBS,
                                "traffic": sh_traffic, "traffic_unit": "bytes per launch (k_shade alone)",

@@ -215,6 +215,9 @@ typedef struct {
     uint64_t finish_nee_rays; /* shadow + MIS rays traced inside the finish kernel                         */
     uint64_t shaded_vertices; /* path vertices the shade kernel processed (hits that survived the miss pre-pass) */
     uint64_t nee_records;     /* of those, vertices that wrote a direct-light record                        */
+    uint64_t any_nodes;       /* counting passes (ptr_profile_enable bit 1): child boxes tested by the any-hit tracer launches */
+    uint64_t any_items;       /* ... leaf items / analytic primitives they tested                            */
+    uint64_t any_rays;        /* ... and the rays they carried                                               */
 } PtrPipelineStats;
 
 /* One entry per kernel family; filled by ptr_profile_read when profiling is on. */

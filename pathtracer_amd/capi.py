@@ -90,7 +90,7 @@ class PtrCounters(C.Structure):
 
 
 class PtrPipelineStats(C.Structure):
-    _fields_ = [(n, u64) for n in ("finish_paths", "finish_nee_rays", "shaded_vertices", "nee_records")]
+    _fields_ = [(n, u64) for n in ("finish_paths", "finish_nee_rays", "shaded_vertices", "nee_records", "any_nodes", "any_items", "any_rays")]
 
 
 class PtrBvhBuildInfo(C.Structure):

@@ -934,12 +934,12 @@ static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int ste
                         launch_ptrace(ctx, s, mio2, upper_at(k), false, false, K_MIS);
                     }
                 } else {
-                launch_ptrace(ctx, s, shadow_io(l, l.queues[3], cnt + 2, cursors + 3 * k + 1, nee_closest), upper_at(k), !nee_closest, nee_closest && ctx->count_traversal, K_SHADOW, est[k][1]);
+                launch_ptrace(ctx, s, shadow_io(l, l.queues[3], cnt + 2, cursors + 3 * k + 1, nee_closest), upper_at(k), !nee_closest, ctx->count_traversal, K_SHADOW, est[k][1]);
                 launch_ptrace(ctx, s, mio, upper_at(k), mis_any, ctx->count_traversal, mis_any ? K_MIS_ANY : K_MIS, est[k][2]);
                 if (exit_records(ctx, l, integrator)) { /* (counting pass: a launch per ray kind) */
                     TraceIO mio2 = exit_io(l, k, true);
                     mio2.any_as_hit = mis_any ? 1 : 0;
-                    launch_ptrace(ctx, s, exit_io(l, k, false), upper_at(k), true, false, K_SHADOW);
+                    launch_ptrace(ctx, s, exit_io(l, k, false), upper_at(k), true, ctx->count_traversal, K_SHADOW);
                     launch_ptrace(ctx, s, mio2, upper_at(k), mis_any, ctx->count_traversal, mis_any ? K_MIS_ANY : K_MIS);
                 }
                 }

@@ -80,7 +80,7 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v) {
  * its index selects: thousands of wavefronts flushing into ONE line at the end of every launch queue up behind
  * each other (atomics on a line are served one at a time).  ptr_counters_read sums the copies. */
 #define CTR_REPLICAS 32
-#define CTR_STRIDE 16 /* unsigned long longs per copy: 128 B >= C_COUNT counters */
+#define CTR_STRIDE 32 /* unsigned long longs per copy: two 128-byte lines, >= CX_END counters */
 __device__ __forceinline__ void ctr_flush(unsigned long long *ctrs, int idx, unsigned v) {
     unsigned s = wave_sum(v);
     if (__lane_id() == 0 && s) atomicAdd(&ctrs[(blockIdx.x & (CTR_REPLICAS - 1)) * CTR_STRIDE + idx], (unsigned long long)s);
@@ -103,8 +103,8 @@ __device__ __forceinline__ void queue_append(int *counter, int *queue, bool pred
 
 enum { C_TOTAL = 0, C_MISS, C_SURF, C_MED, C_LIGHT, C_ZERO, C_SHADOW, C_MIS, C_PROBE, C_CAMERA, C_NODES, C_PRIMS, C_COUNT };
 /* pipeline statistics kept in the same lines, behind the PtrCounters fields (ptr_pipeline_stats_read) */
-enum { CX_FINISH_PATHS = C_COUNT, CX_FINISH_NEE, CX_SHADED, CX_NEE_RECORDS, CX_END };
-static_assert(CX_END <= CTR_STRIDE, "a counter copy is one 128-byte line");
+enum { CX_FINISH_PATHS = C_COUNT, CX_FINISH_NEE, CX_SHADED, CX_NEE_RECORDS, CX_ANY_NODES, CX_ANY_ITEMS, CX_ANY_RAYS, CX_END };
+static_assert(CX_END <= CTR_STRIDE, "a counter copy holds every counter");
 
 /* grid-stride helper: every lane of a wavefront runs the same number of rounds, so the ballots of
  * queue_append / ctr_flush stay convergent; n may live in device memory (written by an earlier

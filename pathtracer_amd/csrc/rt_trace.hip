@@ -39,9 +39,10 @@ __global__ void __launch_bounds__(TRACE_TPB) __attribute__((amdgpu_waves_per_eu(
     OneSource<ANY> src;
     src.io = io;
     persistent_trace_any<OneSource<ANY>, COUNT>(sc, src, &s_stack[threadIdx.x], s_staged, s_top, &tn, &ti);
-    if (COUNT) {
-        ctr_flush(ctrs, C_NODES, tn);
-        ctr_flush(ctrs, C_PRIMS, ti);
+    if (COUNT) { /* any-hit launches are counted apart: their rays end at the first hit and cost a fraction of a closest-hit ray */
+        ctr_flush(ctrs, ANY ? CX_ANY_NODES : C_NODES, tn);
+        ctr_flush(ctrs, ANY ? CX_ANY_ITEMS : C_PRIMS, ti);
+        if (ANY && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctrs[CX_ANY_RAYS], (unsigned long long)(io.n_ptr ? *io.n_ptr : io.n));
     }
 }
 
@@ -109,7 +110,8 @@ void rt_launch_ptrace3(bool count, unsigned blocks, hipStream_t s, const DScene 
 }
 
 void rt_launch_ptrace(bool any, bool count, unsigned blocks, hipStream_t s, const DScene &sc, const TraceIO &io, unsigned long long *ctrs) {
-    if (any) hipLaunchKernelGGL((k_ptrace<true, false>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, io, ctrs);
+    if (any && count) hipLaunchKernelGGL((k_ptrace<true, true>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, io, ctrs);
+    else if (any) hipLaunchKernelGGL((k_ptrace<true, false>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, io, ctrs);
     else if (count) hipLaunchKernelGGL((k_ptrace<false, true>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, io, ctrs);
     else hipLaunchKernelGGL((k_ptrace<false, false>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, io, ctrs);
 }
