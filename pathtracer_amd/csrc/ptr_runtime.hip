@@ -213,24 +213,29 @@ __global__ void __launch_bounds__(TPB) k_hitq_join(const int *cls, const int *q_
 
 /* The four queues a bounce leaves behind - surviving paths, direct-light records, shadow rays, MIS rays - from
  * the route bits k_shade wrote (rt_common.h ROUTE_*).  Like k_miss, a wavefront takes ROUTE_CHUNK x 64 entries and
- * reserves its share of each queue with one atomic per queue (lane q serves queue q). */
+ * reserves its share of each queue with one atomic per queue (lane q serves queue q).
+ * The queue of surviving paths holds path slots; the other three hold direct-light RECORD numbers.  by_place: a vertex's record
+ * is numbered by its place in `queue` (round 3: k_shade writes the records of consecutive queue entries side by side, whatever
+ * their path slots - at later bounces the live slots are a few per 128-byte line); else by the entry itself (exit-point records). */
 #define ROUTE_CHUNK 8
 __global__ void __launch_bounds__(TPB) k_route(const int *n_ptr, const int *queue, const int *route, int *q_next, int *q_nee, int *q_shadow,
-                                               int *q_mis, int *counts) {
+                                               int *q_mis, int *counts, int by_place) {
     const int n = *n_ptr;
     const int lane = __lane_id();
     const unsigned long long lt = (1ull << lane) - 1ull;
     const int wave = (blockIdx.x * TPB + threadIdx.x) >> 6, n_waves = (gridDim.x * TPB) >> 6;
     int *const qs[4] = {q_next, q_nee, q_shadow, q_mis};
     for (long long base = (long long)wave * 64 * ROUTE_CHUNK; base < n; base += (long long)n_waves * 64 * ROUTE_CHUNK) {
-        int slots[ROUTE_CHUNK], bits[ROUTE_CHUNK];
+        int slots[ROUTE_CHUNK], recs[ROUTE_CHUNK], bits[ROUTE_CHUNK];
 #pragma unroll
         for (int c = 0; c < ROUTE_CHUNK; c++) {
             const long long i = base + c * 64 + lane;
             slots[c] = 0;
+            recs[c] = 0;
             bits[c] = 0;
             if (i < n) {
                 slots[c] = queue ? queue[i] : (int)i;
+                recs[c] = by_place ? (int)i : slots[c];
                 bits[c] = route[slots[c]];
             }
         }
@@ -250,24 +255,26 @@ __global__ void __launch_bounds__(TPB) k_route(const int *n_ptr, const int *queu
 #pragma unroll
             for (int c = 0; c < ROUTE_CHUNK; c++) {
                 const unsigned long long m = __ballot((bits[c] >> q) & 1);
-                if ((bits[c] >> q) & 1) qs[q][out + __popcll(m & lt)] = slots[c];
+                if ((bits[c] >> q) & 1) qs[q][out + __popcll(m & lt)] = q == 0 ? slots[c] : recs[c];
                 out += __popcll(m);
             }
         }
     }
 }
 
-/* sum of a direct-light record whose two rays went through the persistent tracer */
-__global__ void __launch_bounds__(TPB) k_nee_resolve(DScene sc, Pipe pp, const int *n_ptr, int n_host, const int *queue,
+/* sum of a direct-light record whose two rays went through the persistent tracer; q_hit: the bounce's queue of shaded
+ * vertices, whose entry r is the path slot record r belongs to */
+__global__ void __launch_bounds__(TPB) k_nee_resolve(DScene sc, Pipe pp, const int *n_ptr, int n_host, const int *queue, const int *q_hit,
                                                      unsigned long long *ctrs, int shadow_closest) {
     NeeCtr ctr;
     ctr.shadow = ctr.mis = ctr.zero = 0;
     GRID_STRIDE_BEGIN(n_ptr, n_host)
     if (i < n) {
-        int slot = queue[i];
+        const int r = queue[i];
+        const int slot = q_hit[r];
         NeeRec rec;
-        nee_load(pp, slot, &rec);
-        soa_load<NEE_RES_BEGIN, NEE_RES_END>(pp.nee, pp.cap, slot, &rec);
+        nee_load(pp, r, &rec);
+        soa_load<NEE_RES_BEGIN, NEE_RES_END>(pp.nee, pp.cap, r, &rec);
         f3 Ld = nee_resolve_traced(sc, rec, ctr, shadow_closest != 0);
         PathRec ps;
         soa_load<0, 3>(pp.paths, pp.cap, slot, &ps);
@@ -735,12 +742,12 @@ static void enqueue_shade(PtrContext *ctx, Lane &l, const PassParams &prm, const
         rt_launch_shade_sss(tail_blocks, s, a);
     } else rt_launch_shade(stride_blocks, s, a);
     hipLaunchKernelGGL(k_route, dim3(clampu(nblocks((n_upper + ROUTE_CHUNK - 1) / ROUTE_CHUNK), 32, 2048)), dim3(TPB), 0, s, (const int *)hit_count,
-                       (const int *)l.queues[5], (const int *)l.pipe.hprim, q_next, l.queues[2], l.queues[3], l.queues[4], cnt);
+                       (const int *)l.queues[5], (const int *)l.pipe.hprim, q_next, l.queues[2], l.queues[3], l.queues[4], cnt, 1);
     if (a.chains.exit.planes) { /* the queues of the exit-point records, from the flags the tail kernel left per chain */
         int *scnt = l.sss_counts + SSS_COUNTER_STRIDE * cslot;
         const int upper = n_upper < l.sss_cap ? n_upper : l.sss_cap;
         hipLaunchKernelGGL(k_route, dim3(clampu(nblocks((upper + ROUTE_CHUNK - 1) / ROUTE_CHUNK), 32, 2048)), dim3(TPB), 0, s, (const int *)(scnt + 1),
-                           (const int *)nullptr, (const int *)l.sss_route, l.sss_q[0] /* (bit 0 is never set) */, l.sss_q[0], l.sss_q[1], l.sss_q[2], scnt + SSS_EXIT_COUNTS);
+                           (const int *)nullptr, (const int *)l.sss_route, l.sss_q[0] /* (bit 0 is never set) */, l.sss_q[0], l.sss_q[1], l.sss_q[2], scnt + SSS_EXIT_COUNTS, 0);
     }
 }
 /* the exit-point records of the bounce summed into L (after enqueue_resolve: their term follows the vertex's own) */
@@ -764,7 +771,7 @@ static void enqueue_nee_walks(PtrContext *ctx, Lane &l, int n_upper, int cslot) 
     }
     {
         ProfScope ps(ctx, s, K_MIS, 0);
-        rt_launch_mis_walk(stride_blocks, s, ctx->sc, l.pipe, (const int *)(cnt + 1), 0, (const int *)l.queues[2], ctx->ctrs);
+        rt_launch_mis_walk(stride_blocks, s, ctx->sc, l.pipe, (const int *)(cnt + 1), 0, (const int *)l.queues[2], (const int *)l.queues[5], ctx->ctrs);
     }
 }
 static void enqueue_resolve(PtrContext *ctx, Lane &l, int n_upper, int cslot, bool shadow_closest = false) {
@@ -772,7 +779,7 @@ static void enqueue_resolve(PtrContext *ctx, Lane &l, int n_upper, int cslot, bo
     int *cnt = l.counts + 4 * cslot;
     ProfScope ps(ctx, s, K_RESOLVE, 0);
     hipLaunchKernelGGL(k_nee_resolve, dim3(clampu(nblocks(n_upper), 32, 2048)), dim3(TPB), 0, s, ctx->sc, l.pipe, (const int *)(cnt + 1), 0,
-                       (const int *)l.queues[2], ctx->ctrs, shadow_closest ? 1 : 0);
+                       (const int *)l.queues[2], (const int *)l.queues[5], ctx->ctrs, shadow_closest ? 1 : 0);
 }
 
 /* PTR_DEBUG_SYNC=1: wait for the lane after a stage and report the stage a failure belongs to (a pass queues ~10 launches

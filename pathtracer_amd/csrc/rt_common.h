@@ -181,7 +181,7 @@ void rt_launch_finish_sss(unsigned blocks, hipStream_t s, const FinishArgs &a); 
 void rt_launch_shadow_walk(unsigned blocks, hipStream_t s, const DScene &sc, const Pipe &pp, const int *n_ptr, int n_host, const int *queue,
                            unsigned long long *ctrs); /* rt_walk.hip */
 void rt_launch_mis_walk(unsigned blocks, hipStream_t s, const DScene &sc, const Pipe &pp, const int *n_ptr, int n_host, const int *queue,
-                        unsigned long long *ctrs);
+                        const int *q_hit, unsigned long long *ctrs);
 void rt_launch_ptrace2any(unsigned blocks, hipStream_t s, const DScene &sc, const TraceIO &a, const TraceIO &b);
 void rt_launch_ptrace3(bool count, unsigned blocks, hipStream_t s, const DScene &sc, const TraceIO &path, const TraceIO &shadow, const TraceIO &mis,
                        unsigned long long *ctrs);

@@ -52,7 +52,7 @@ extern __shared__ float s_dyn_lobes[];
 /* The deferred vertices from where k_shade<SSS_DEFER> left them (dev_path.h sss_continue), MODE = SSS_BEGIN / SSS_TAIL /
  * SSS_INPLACE.  Returns false if the vertex is not this launch's (SSS_TAIL: its chain is not settled). */
 template <int MODE>
-__device__ __forceinline__ bool tail_slot(const DScene &sc, const Pipe &pp, const PassParams &prm, int slot, float *lobes, VertexCtr &ctr, SssCtx &sss) {
+__device__ __forceinline__ bool tail_slot(const DScene &sc, const Pipe &pp, const PassParams &prm, int slot, int rec_at, float *lobes, VertexCtr &ctr, SssCtx &sss) {
     const int cap = pp.cap;
     const int word = pp.hprim[slot];
     const int hit_prim = word & SHADE_PRIM_MASK, own_route = (word >> SHADE_ROUTE_SHIFT) & (ROUTE_NEE | ROUTE_SHADOW | ROUTE_MIS);
@@ -70,12 +70,12 @@ __device__ __forceinline__ bool tail_slot(const DScene &sc, const Pipe &pp, cons
     if (!to.settled) return false;
     if (to.has_extra) { /* direct light at the exit point, resolved in this lane: it follows the vertex's own term in L */
         if (own_route & ROUTE_NEE) {
-            uint32_t *fw = pp.nee + plane_at(NEE_WORDS, slot, NEE_W(flags));
+            uint32_t *fw = pp.nee + plane_at(NEE_WORDS, rec_at, NEE_W(flags));
             *fw |= NEE_EXTRA;
             float *ex = reinterpret_cast<float *>(pp.nee);
-            ex[plane_at(NEE_WORDS, slot, NEE_W(extra))] = to.L_extra.x;
-            ex[plane_at(NEE_WORDS, slot, NEE_W(extra) + 1)] = to.L_extra.y;
-            ex[plane_at(NEE_WORDS, slot, NEE_W(extra) + 2)] = to.L_extra.z;
+            ex[plane_at(NEE_WORDS, rec_at, NEE_W(extra))] = to.L_extra.x;
+            ex[plane_at(NEE_WORDS, rec_at, NEE_W(extra) + 1)] = to.L_extra.y;
+            ex[plane_at(NEE_WORDS, rec_at, NEE_W(extra) + 2)] = to.L_extra.z;
         } else {
             f3 L = ld3(ps.L);
             L += to.L_extra;
@@ -97,15 +97,15 @@ __device__ __forceinline__ bool tail_slot(const DScene &sc, const Pipe &pp, cons
 }
 
 template <int MODE>
-__device__ __forceinline__ void shade_slot(const DScene &sc, const Pipe &pp, const PassParams &prm, int slot, int hit_prim, float *lobes, VertexCtr &ctr,
+__device__ __forceinline__ void shade_slot(const DScene &sc, const Pipe &pp, const PassParams &prm, int slot, int rec_at, int hit_prim, float *lobes, VertexCtr &ctr,
                                            const SssCtx &sss, unsigned &shaded, unsigned &nee_recs SH_STATS_PARAM) {
     const int cap = pp.cap;
     PathRec ps;
     soa_load<0, PATH_WORDS>(pp.paths, cap, slot, &ps);
 #ifdef SH_STATS
-    const NeeToPlanes rec = {reinterpret_cast<float *>(pp.nee), slot, prm.nee_p1 != 0, shs};
+    const NeeToPlanes rec = {reinterpret_cast<float *>(pp.nee), rec_at, prm.nee_p1 != 0, shs};
 #else
-    const NeeToPlanes rec = {reinterpret_cast<float *>(pp.nee), slot, prm.nee_p1 != 0};
+    const NeeToPlanes rec = {reinterpret_cast<float *>(pp.nee), rec_at, prm.nee_p1 != 0};
 #endif
     f3 ro(pp.ro[slot], pp.ro[cap + slot], pp.ro[2 * cap + slot]);
     f3 rd(pp.rd[slot], pp.rd[cap + slot], pp.rd[2 * cap + slot]);
@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(TPB)
             __syncthreads();
             for (int j = threadIdx.x; j < SSS_CHUNK && base + j < n; j += TPB) {
                 const int slot = queue ? queue[base + j] : base + j;
-                if (pp.hprim[slot] & SHADE_DEFERRED) s_list[atomicAdd(&s_count, 1)] = slot;
+                if (pp.hprim[slot] & SHADE_DEFERRED) s_list[atomicAdd(&s_count, 1)] = base + j; /* the vertex's place in the queue = its direct-light record */
             }
             __syncthreads();
             const int cnt = s_count;
@@ -195,19 +195,20 @@ __global__ void __launch_bounds__(TPB)
                 __syncthreads();
             }
             for (int j = threadIdx.x; j < cnt; j += TPB) {
-                const int slot = s_list[j];
+                const int at = s_list[j];
+                const int slot = queue ? queue[at] : at;
                 if (BEGIN) {
                     const int cj = s_base + j;
                     const bool has = cj < chains.cap;
-                    pp.nee[plane_at(NEE_WORDS, slot, SSS_CHAIN_WORD)] = (uint32_t)(has ? cj : -1);
+                    pp.nee[plane_at(NEE_WORDS, at, SSS_CHAIN_WORD)] = (uint32_t)(has ? cj : -1);
                     if (has) {
                         if (chains.exit.route) chains.exit.route[cj] = 0; /* no exit-point record yet */
                         sss.chain = ChainRef{chains.planes, cj};
-                        tail_slot<SSS_BEGIN>(sc, pp, prm, slot, &s_lobes[threadIdx.x], ctr, sss);
+                        tail_slot<SSS_BEGIN>(sc, pp, prm, slot, at, &s_lobes[threadIdx.x], ctr, sss);
                     }
                 } else {
-                    sss.chain = ChainRef{chains.planes, chains.planes ? (int)pp.nee[plane_at(NEE_WORDS, slot, SSS_CHAIN_WORD)] : -1};
-                    tail_slot<MODE == SSS_TAIL ? SSS_TAIL : SSS_INPLACE>(sc, pp, prm, slot, &s_lobes[threadIdx.x], ctr, sss);
+                    sss.chain = ChainRef{chains.planes, chains.planes ? (int)pp.nee[plane_at(NEE_WORDS, at, SSS_CHAIN_WORD)] : -1};
+                    tail_slot<MODE == SSS_TAIL ? SSS_TAIL : SSS_INPLACE>(sc, pp, prm, slot, at, &s_lobes[threadIdx.x], ctr, sss);
                 }
             }
             __syncthreads();
@@ -220,7 +221,7 @@ __global__ void __launch_bounds__(TPB)
 #endif
         if (i < n) {
             const int slot = queue ? queue[i] : i;
-            shade_slot<MODE>(sc, pp, prm, slot, pp.hprim[slot], &s_lobes[threadIdx.x], ctr, sss, shaded, nee_recs SH_STATS_ARG);
+            shade_slot<MODE>(sc, pp, prm, slot, i, pp.hprim[slot], &s_lobes[threadIdx.x], ctr, sss, shaded, nee_recs SH_STATS_ARG);
         }
 #ifdef SH_STATS
         SH_T(shs, SH_STORE);

@@ -20,18 +20,18 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(WALK_W
     ctr.shadow = ctr.mis = ctr.zero = 0;
     GRID_STRIDE_BEGIN(n_ptr, n_host)
     if (i < n) {
-        const int slot = queue[i];
+        const int r = queue[i]; /* direct-light record = the vertex's place in the bounce's queue of shaded vertices (k_route) */
         NeeRec rec;
-        nee_load(pp, slot, &rec);
+        nee_load(pp, r, &rec);
         nee_shadow<true>(sc, &rec, ctr, ls);
-        soa_store<WORD_OF(NeeRec, LiA), WORD_OF(NeeRec, LiA) + 3>(pp.nee, pp.cap, slot, &rec);
+        soa_store<WORD_OF(NeeRec, LiA), WORD_OF(NeeRec, LiA) + 3>(pp.nee, pp.cap, r, &rec);
     }
     GRID_STRIDE_END
     ctr_flush(ctrs, C_SHADOW, ctr.shadow);
 }
 
 __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(WALK_WAVES, WALK_WAVES))) k_mis_walk(DScene sc, Pipe pp, const int *n_ptr, int n_host, const int *queue,
-                                                  unsigned long long *ctrs) {
+                                                  const int *q_hit, unsigned long long *ctrs) {
     __shared__ int s_stack[LDS_STACK * TRACE_TPB];
     LaneStack ls;
     ls.lds = &s_stack[threadIdx.x];
@@ -39,9 +39,10 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(WALK_W
     ctr.shadow = ctr.mis = ctr.zero = 0;
     GRID_STRIDE_BEGIN(n_ptr, n_host)
     if (i < n) {
-        int slot = queue[i];
+        const int r = queue[i];
+        const int slot = q_hit[r]; /* the path the record belongs to */
         NeeRec rec;
-        nee_load(pp, slot, &rec);
+        nee_load(pp, r, &rec);
         f3 Ld = nee_mis_resolve<true>(sc, rec, ctr, ls);
         PathRec ps;
         soa_load<0, 3>(pp.paths, pp.cap, slot, &ps);
@@ -62,6 +63,6 @@ void rt_launch_shadow_walk(unsigned blocks, hipStream_t s, const DScene &sc, con
     hipLaunchKernelGGL(k_shadow_walk, dim3(blocks), dim3(TPB), 0, s, sc, pp, n_ptr, n_host, queue, ctrs);
 }
 void rt_launch_mis_walk(unsigned blocks, hipStream_t s, const DScene &sc, const Pipe &pp, const int *n_ptr, int n_host, const int *queue,
-                        unsigned long long *ctrs) {
-    hipLaunchKernelGGL(k_mis_walk, dim3(blocks), dim3(TPB), 0, s, sc, pp, n_ptr, n_host, queue, ctrs);
+                        const int *q_hit, unsigned long long *ctrs) {
+    hipLaunchKernelGGL(k_mis_walk, dim3(blocks), dim3(TPB), 0, s, sc, pp, n_ptr, n_host, queue, q_hit, ctrs);
 }
