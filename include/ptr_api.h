@@ -218,10 +218,12 @@ typedef struct {
     uint64_t any_nodes;       /* counting passes (ptr_profile_enable bit 1): child boxes tested by the any-hit tracer launches */
     uint64_t any_items;       /* ... leaf items / analytic primitives they tested                            */
     uint64_t any_rays;        /* ... and the rays they carried                                               */
+    uint64_t fast_top_deferred; /* closest-hit rays that started in the fast top-level tree and were walked again through the
+                                 * reference's tree, because their answer could depend on its order (dev_trace.h) */
 } PtrPipelineStats;
 
 /* One entry per kernel family; filled by ptr_profile_read when profiling is on. */
-#define PTR_PROF_KERNELS 11
+#define PTR_PROF_KERNELS 12
 typedef struct {
     char name[32];
     uint64_t launches;

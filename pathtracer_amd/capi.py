@@ -19,7 +19,7 @@ SHAPE_SPHERE, SHAPE_RECTANGLE, SHAPE_DISK, SHAPE_BOX, SHAPE_MESH, SHAPE_PARTICLE
 SHAPE_SPHERE_PROCEDURAL, SHAPE_BOX_PROCEDURAL, SHAPE_COMPONENT_PROCEDURAL = 6, 7, 8
 MAT_NONE, MAT_MATTE, MAT_MIRROR, MAT_GLASS, MAT_METAL, MAT_TRANSLUCENT, MAT_PLASTIC, MAT_UBER = range(8)
 MAT_SUBSURFACE, MAT_KDSUBSURFACE, MAT_PLAYGROUND, MAT_DISNEY = 8, 9, 10, 11
-PROF_KERNELS = 11
+PROF_KERNELS = 12
 
 f32, i32, u64, i64 = C.c_float, C.c_int32, C.c_uint64, C.c_int64
 fptr, iptr = C.POINTER(C.c_float), C.POINTER(C.c_int32)
@@ -90,7 +90,7 @@ class PtrCounters(C.Structure):
 
 
 class PtrPipelineStats(C.Structure):
-    _fields_ = [(n, u64) for n in ("finish_paths", "finish_nee_rays", "shaded_vertices", "nee_records", "any_nodes", "any_items", "any_rays")]
+    _fields_ = [(n, u64) for n in ("finish_paths", "finish_nee_rays", "shaded_vertices", "nee_records", "any_nodes", "any_items", "any_rays", "fast_top_deferred")]
 
 
 class PtrBvhBuildInfo(C.Structure):

@@ -28,12 +28,13 @@ struct Node128 {
 /* Node of the top-level BVH over primitives: the reference's own tree (primitive.cpp:537-582),
  * kept because a few results depend on its visiting order.  Leaf: left = -1, handles
  * order[first .. first+n). */
-struct TopNode { /* 96 B = 6 float4; nodes are numbered breadth first (ptr_build.cpp), node 0 is the root */
+struct TopNode { /* 96 B = 6 float4; each tree's nodes are numbered breadth first (ptr_build.cpp), node 0 is the reference tree's root */
     float bmin[3];
     int32_t left;
     float bmax[3];
     int32_t right;
-    int32_t first, n, pad[2];
+    int32_t first, n;
+    int32_t pad[2]; /* inner node: the primitive of the left / right child if that child is a one-primitive leaf, else -1 (ptr_build.cpp) */
     /* copies of the two children's boxes (inner nodes): one step of the persistent tracer - this node's box, then both
      * children's - reads one record instead of three (dev_trace.h) */
     float lmin[3], lmax[3], rmin[3], rmax[3];
@@ -139,7 +140,10 @@ struct DScene {
     int32_t env_w, env_h, env_nu, env_nv;
     int32_t n_prims, n_lights, n_nodes, n_items;
     int32_t view_medium, has_env;
-    int32_t n_top;
+    int32_t n_top;      /* nodes of the reference's tree, top[0 .. n_top) */
+    int32_t top_fast;   /* root of the fast tree over the same primitives (ptr_build.cpp build_fast_top), top[top_fast .. top_fast + n_top_fast); 0: none */
+    int32_t n_top_fast;
+    int32_t trace_waves; /* which build of the persistent tracer the scene's launches use (rt_trace.hip): PT_WAVES or PT_WAVES_WIDE */
 };
 
 struct DCamera {

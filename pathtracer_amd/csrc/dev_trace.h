@@ -36,8 +36,13 @@ struct TraceIO {
     int tile_words, w_o, w_d, w_prim, w_t;
     int any_as_hit; /* any-hit launch whose result is read like a closest hit's prim word: some prim id / -1 */
     int w_face1;    /* tiled planes, closest hit: 1 + the word that receives the face (0: the face is not stored) */
+    /* fast top level (persistent_trace<.., FAST = true>): the closest-hit rays whose answer may need the reference's order are
+     * left here - their slots, counted in *fb_count - for a second launch that walks the reference's tree */
+    int *fb_queue, *fb_count;
+    int is_fallback; /* this IS that second launch (its ray count goes to the CX_FAST_DEFERRED statistic) */
 };
 
+#define GEOM_BOTTOM INT32_MIN /* stack entry under a mesh's / cloud's own (= BVH_NO_CHILD, which is never pushed) */
 enum { TM_IDLE = 0, TM_TOP = 1, TM_TOPLEAF = 2, TM_GEOM = 3, TM_DONE = 4 /* CONTINUES sources: the ray has its answer and waits for src.advance */ };
 
 #define PT_PUSH(v)                                          \
@@ -113,9 +118,10 @@ PD void trace_io_store(const TraceIO &io, bool any, int slot, bool hit, int hp, 
  * (closest hit), shadow rays (any hit), MIS rays (closest hit) - served by ONE launch: a launch
  * lasts about as long as its longest ray, so three launches per bounce pay that tail three times
  * and run their last waves on a mostly empty GPU. */
-template <bool ANY>
+template <bool ANY, bool WITH_BARY = false>
 struct OneSource {
     static constexpr bool CONTINUES = false;
+    static constexpr bool BARY = WITH_BARY; /* the launch stores barycentrics (the stand-alone ptr_trace_closest; the pipeline rebuilds its hits from prim / face / t) */
     TraceIO io;
     int n_rays;
     int *counter;
@@ -127,9 +133,11 @@ struct OneSource {
     PD void store(int, int slot, bool hit, int hp, int hf, float tmax, float hb0, float hb1, unsigned rn, unsigned ri) const {
         trace_io_store<COUNT>(io, ANY, slot, hit, hp, hf, tmax, hb0, hb1, rn, ri);
     }
+    PD void defer(int, int slot) const { io.fb_queue[atomicAdd(io.fb_count, 1)] = slot; } /* (rare: one atomic per ray is fine) */
 };
 struct ThreeSources {
     static constexpr bool CONTINUES = false;
+    static constexpr bool BARY = false;
     TraceIO path, shadow, mis; /* path.counter is the fetch cursor of the launch */
     int n0, n01, n012;
     int *counter;
@@ -152,11 +160,13 @@ struct ThreeSources {
         else if (tag == 1) trace_io_store<COUNT>(shadow, true, slot, hit, hp, hf, tmax, hb0, hb1, rn, ri);
         else trace_io_store<COUNT>(mis, false, slot, hit, hp, hf, tmax, hb0, hb1, rn, ri);
     }
+    PD void defer(int, int) const {} /* (never launched with FAST) */
 };
 
 /* Two any-hit queues in one launch: the shadow rays and - where any hit answers them (ptr_runtime.hip) - the MIS rays of a bounce */
 struct TwoAny {
     static constexpr bool CONTINUES = false;
+    static constexpr bool BARY = false;
     TraceIO a, b; /* a.counter is the fetch cursor of the launch */
     int n0, n01;
     int *counter;
@@ -176,6 +186,7 @@ struct TwoAny {
         if (tag == 0) trace_io_store<COUNT>(a, true, slot, hit, hp, hf, tmax, hb0, hb1, rn, ri);
         else trace_io_store<COUNT>(b, true, slot, hit, hp, hf, tmax, hb0, hb1, rn, ri);
     }
+    PD void defer(int, int) const {} /* (any-hit rays are never deferred) */
 };
 
 /* A source whose rays CONTINUE: when a ray has its answer the lane does not take the next ray of the queue but waits (TM_DONE)
@@ -185,6 +196,7 @@ struct TwoAny {
  * ChainSource: the BSSRDF probe chains (dev_bssrdf.h): ray = the chain's current segment, advance = chain_advance. */
 struct ChainSource {
     static constexpr bool CONTINUES = true;
+    static constexpr bool BARY = false;
     uint32_t *planes;
     const int *n_ptr;
     int n_rays;
@@ -210,6 +222,7 @@ struct ChainSource {
         *tmax = 1 - kShadowEpsilon;
         return chain_advance(sc, c, hit ? hp : -1, hf, t, ro, rd);
     }
+    PD void defer(int, int) const {} /* (never launched with FAST: a probe segment is not a unit vector) */
 };
 
 /* PT_STATS (diagnostic build only, tools/gpu_tracestats.py): where the lanes and the cycles of the persistent tracer go.
@@ -235,7 +248,30 @@ static __device__ unsigned long long g_pt_stats[PS_N];
 #ifndef PT_PREFETCH
 #define PT_PREFETCH 0
 #endif
-template <class Source, bool COUNT>
+/* ---- fast top level (round 3; FAST = true) ----------------------------------------------------------------------
+ * A scene of more than a handful of primitives carries a second tree over them, built for speed (ptr_build.cpp
+ * build_fast_top; DScene::top_fast): in a room of a hundred primitives a ray steps through ~25 nodes of the reference's
+ * median-split tree with its random axes.  A ray walks the fast tree when its answer provably does not need the reference's order:
+ *   any hit      always: tMax does not change before the walk ends, so every primitive is tested with the same tMax and
+ *                reached through the same test of its own bounds (made here at the leaf, as the reference's one-primitive
+ *                leaves make it) whatever the order;
+ *   closest hit  if its direction is a unit vector to rounding (an SDF shape measures t along the normalised direction,
+ *                procedural.cpp:238: for other rays its answer can EXCEED the tMax it was given, and then everything
+ *                depends on order).  The walk keeps tbest = the smallest accepted t and tests everything against the
+ *                wider bound tmax = G = max(entry distance of the winner's own bounds, tbest * (1 + 1e-5)).  The
+ *                reference's walk accepts a hit when t <= tMax and its bounds are entered before tMax, and its tMax only
+ *                falls: it returns the candidate of smallest t - unless it culled that candidate by its bounds (possible
+ *                only if another candidate lies in front of those bounds: t < entry distance), or two candidates are equal
+ *                in t (the later wins).  Both need a second candidate with t < G, and every way such a candidate can show
+ *                up defers the ray: an accepted t above tbest, a superseded tbest below the new G, a hit whose own bounds
+ *                lie behind the bound of the walk, a mesh winner whose bounds lie behind its own hit.  (What was rejected
+ *                or culled under an earlier bound lies beyond that bound, which was at least the tbest of the time - so if
+ *                it lies below the final G, so does a superseded tbest.)
+ * A deferred ray's slot goes to the launch's fallback queue (TraceIO::fb_queue); a second launch (FAST = false) walks those rays
+ * through the reference's tree from their start: the same answer as ever, for every ray.  The fast tree's boxes are wider than
+ * the primitives' bounds (they hold every hit point a primitive can report), so culling by them loses no candidate. */
+#define FZ_WIDEN 1.00001f
+template <class Source, bool COUNT, bool FAST = false>
 PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *staged, const float4 *top_staged, unsigned *total_nodes,
                          unsigned *total_items) {
     int ovf[OVF_STACK];
@@ -251,11 +287,15 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *s
     f3 ro, rd, inv;
     TriRay tr;
     tr.kx = tr.ky = tr.kz = 0; tr.Sx = tr.Sy = tr.Sz = 0;
-    float tmax = 0, hb0 = 0, hb1 = 0;
+    float tmax = 0, hb0 = 0, hb1 = 0; /* (hb0, hb1: only sources with BARY keep them - two registers the pipeline's launches do without) */
     int hp = -1, hf = -1;
     bool hit = false;
-    int tnode = -1, leaf_pos = 0, leaf_end = 0, cp = -1, node = 0, sp = 0, sp_base = 0;
+    /* (in TM_TOPLEAF tnode holds the end of the leaf's handle range: a node is only named again by the pop that leaves the leaf) */
+    int tnode = -1, leaf_pos = 0, cp = -1, node = 0, sp = 0;
     unsigned rn = 0, ri = 0; /* per-ray work (COUNT) */
+    bool fresh = false; /* top level: tnode was reached by descent from its parent, where its box has just passed with this tMax */
+    float tbest = 0; /* FAST closest-hit walk: the smallest accepted t (tmax is then the slightly wider bound everything is tested with) */
+    const int top_root = FAST ? sc.top_fast : 0;
 
     const int n_rays = src.total();
     int pool_pos = 0, pool_end = 0; /* wave-uniform */
@@ -275,6 +315,21 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *s
         }                                                                            \
     } while (0)
 #define PT_ANY (src.is_any(tag))
+#define PT_FZ_CLOSEST (FAST && !PT_ANY)
+/* the ray goes to the fallback queue: its answer may depend on the reference's order */
+#define PT_DEFER()                                                                   \
+    do {                                                                             \
+        if (COUNT) { *total_nodes += rn; *total_items += ri; }                       \
+        src.defer(tag, slot);                                                        \
+        mode = TM_IDLE;                                                              \
+        slot = -1;                                                                   \
+    } while (0)
+/* the ray leaves a mesh / cloud: a hit it took there becomes the bound for what follows */
+#define PT_LEAVE_GEOM()                                                              \
+    do {                                                                             \
+        if (PT_FZ_CLOSEST && hit && hp == cp) tmax = tbest * FZ_WIDEN;               \
+        mode = TM_TOPLEAF;                                                           \
+    } while (0)
 
     for (;;) {
         PS_ADD(PS_OUTER, 1);
@@ -291,7 +346,8 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *s
                         rn = 0; ri = 0;
                         sp = 0;
                         PT_PUSH(-1);
-                        tnode = sc.n_top == 0 ? -1 : 0; /* (an empty scene: the walk ends at its first step) */
+                        tnode = sc.n_top == 0 ? -1 : top_root; /* (an empty scene: the walk ends at its first step) */
+                        fresh = false;
                         mode = TM_TOP;
                     } else {
                         mode = TM_IDLE;
@@ -328,9 +384,11 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *s
                     rn = 0; ri = 0;
                     sp = 0;
                     if (sc.n_top == 0) PT_FINISH();
+                    else if (PT_FZ_CLOSEST && !(absr(dot(rd, rd) - 1.f) < 1e-5f)) PT_DEFER(); /* not a unit direction: the reference's tree */
                     else {
                         PT_PUSH(-1);
-                        tnode = 0;
+                        tnode = top_root;
+                        fresh = false;
                         mode = TM_TOP;
                     }
                 }
@@ -349,70 +407,133 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *s
         if (__popcll(in_top) >= PT_TOP_BATCH || __ballot(mode == TM_GEOM) == 0)
         while (mode == TM_TOP || mode == TM_TOPLEAF) {
             PS_WAVE_IT(PS_TOP_IT, PS_TOP_LANES);
+            int p = -1;            /* the primitive this iteration tests, if any */
+            bool leaf_box = false; /* ... after its leaf's box, which is the primitive's own bounds */
             if (mode == TM_TOP) {
-                if (tnode == -1) { PT_FINISH(); break; }
-                /* one record per step: this node's box and, for an inner node, copies of both children's (TopNode);
-                 * the upper levels come from the block's LDS copy */
-                float4 q0, q1, q2, q3, q4, q5;
-                if (top_staged && tnode < TOP_LDS_NODES) {
-                    const float4 *np = top_staged + tnode * TOP_LDS_ROW;
-                    q0 = np[0]; q1 = np[1]; q2 = np[2]; q3 = np[3]; q4 = np[4]; q5 = np[5];
-                } else {
-                    const float4 *np = reinterpret_cast<const float4 *>(sc.top + tnode);
-                    q0 = np[0]; q1 = np[1]; q2 = np[2]; q3 = np[3]; q4 = np[4]; q5 = np[5];
-                }
-                const int nd_left = __float_as_int(q0.w), nd_right = __float_as_int(q1.w);
-                float te;
-                if (COUNT) rn += 1;
-                if (slab_test6(q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, ro, inv, tmax, &te)) {
-                    if (nd_left < 0) {
-                        leaf_pos = __float_as_int(q2.x);
-                        leaf_end = leaf_pos + __float_as_int(q2.y);
-                        mode = TM_TOPLEAF;
-                    } else {
-                        float tl0, tr0;
-                        if (COUNT) rn += 2;
-                        bool visitL = slab_test6(q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, ro, inv, tmax, &tl0);
-                        bool visitR = slab_test6(q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, ro, inv, tmax, &tr0);
-                        if (visitR && visitL) {
-                            int first, second;
-                            if (tr0 < tl0) { first = nd_right; second = nd_left; }
-                            else { first = nd_left; second = nd_right; }
-                            PT_PUSH(second);
-                            tnode = first;
-                        } else if (visitL) tnode = nd_left;
-                        else if (visitR) tnode = nd_right;
-                        else tnode = PT_POP();
-                    }
-                } else tnode = PT_POP();
-            } else {
-                if (leaf_pos == leaf_end) {
-                    tnode = PT_POP();
-                    mode = TM_TOP;
-                } else {
-                    const int p = sc.order[leaf_pos++];
-                    const DPrim &pr = sc.prims[p];
-                    if (pr.type == SH_MESH || pr.type == SH_CLOUD) {
-                        cp = p;
-                        node = pr.root;
-                        sp_base = sp;
-                        mode = TM_GEOM;
-                    } else {
-                        float t;
-                        int face;
-                        if (COUNT) ri += 1;
-#ifdef PT_STATS
-                        const long long cp0_ = clock64();
-                        PS_WAVE_IT(PS_TOPPRIM_IT, PS_TOPPRIM_LANES);
-#endif
-                        const bool ph_ = shape_hit_t(sc, pr, ro, rd, tmax, &t, &face);
-#ifdef PT_STATS
-                        st_[PS_CYC_TOPPRIM] += clock64() - cp0_;
-#endif
-                        if (ph_) {
-                            tmax = t; hp = p; hf = face; hb0 = 0; hb1 = 0; hit = true;
-                            if (PT_ANY) { PT_FINISH(); break; }
+                if (tnode == -1) {
+                    if (PT_FZ_CLOSEST && hit) {
+                        /* a mesh / cloud winner: would the reference have reached it?  (an analytic winner: G says so) */
+                        const DPrim &pw = sc.prims[hp];
+                        float te;
+                        if ((pw.type == SH_MESH || pw.type == SH_CLOUD) &&
+                            !slab_test6(pw.bmin[0], pw.bmin[1], pw.bmin[2], pw.bmax[0], pw.bmax[1], pw.bmax[2], ro, inv, tbest, &te)) {
+                            PT_DEFER();
+                            break;
                         }
+                        tmax = tbest;
+                    }
+                    PT_FINISH();
+                    break;
+                }
+                if (tnode < -1) {
+                    /* a leaf of one primitive, named by its parent (TopNode::pad): no record to read.  Reached by descent, its box
+                     * has just passed at the parent with this same tMax; popped, it is tested again with the tMax of now, as the
+                     * reference does (IntersectNode at the pop).  FAST: the primitive's bounds are tested below in any case. */
+                    p = -tnode - 2;
+                    leaf_box = !FAST && !fresh;
+                    leaf_pos = tnode = 0;
+                    mode = TM_TOPLEAF;
+                } else {
+                    /* one record per step: this node's box and, for an inner node, copies of both children's (TopNode);
+                     * the upper levels of the tree this kernel's rays walk come from the block's LDS copy */
+                    float4 q0, q1, q2, q3, q4, q5;
+                    const int tl = tnode - top_root;
+                    if (top_staged && tl < TOP_LDS_NODES) {
+                        const float4 *np = top_staged + tl * TOP_LDS_ROW;
+                        q0 = np[0]; q1 = np[1]; q2 = np[2]; q3 = np[3]; q4 = np[4]; q5 = np[5];
+                    } else {
+                        const float4 *np = reinterpret_cast<const float4 *>(sc.top + tnode);
+                        q0 = np[0]; q1 = np[1]; q2 = np[2]; q3 = np[3]; q4 = np[4]; q5 = np[5];
+                    }
+                    const int nd_left = __float_as_int(q0.w), nd_right = __float_as_int(q1.w);
+                    float te;
+                    /* (a node reached by descent passed this very test - same box, same ray, same tMax - one step ago, at its parent) */
+                    bool enter = fresh;
+                    if (!enter) {
+                        if (COUNT) rn += 1;
+                        enter = slab_test6(q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, ro, inv, tmax, &te);
+                    }
+                    fresh = false;
+                    if (enter) {
+                        if (nd_left < 0) {
+                            leaf_pos = __float_as_int(q2.x);
+                            tnode = leaf_pos + __float_as_int(q2.y);
+                            mode = TM_TOPLEAF;
+                        } else {
+                            float tl0, tr0;
+                            if (COUNT) rn += 2;
+                            const bool visitL = slab_test6(q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, ro, inv, tmax, &tl0);
+                            const bool visitR = slab_test6(q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, ro, inv, tmax, &tr0);
+                            const int pl = __float_as_int(q2.z), pr_ = __float_as_int(q2.w);
+                            const int ref_l = pl >= 0 ? -pl - 2 : nd_left, ref_r = pr_ >= 0 ? -pr_ - 2 : nd_right;
+                            if (visitR && visitL) {
+                                int first, second;
+                                if (tr0 < tl0) { first = ref_r; second = ref_l; }
+                                else { first = ref_l; second = ref_r; }
+                                PT_PUSH(second);
+                                tnode = first;
+                                fresh = true;
+                            } else if (visitL) { tnode = ref_l; fresh = true; }
+                            else if (visitR) { tnode = ref_r; fresh = true; }
+                            else tnode = PT_POP();
+                        }
+                    } else tnode = PT_POP();
+                }
+            }
+            if (mode == TM_TOPLEAF) { /* (not `else`: a leaf step and its first primitive share an iteration) */
+                if (p < 0) {
+                    if (leaf_pos == tnode) {
+                        tnode = PT_POP();
+                        fresh = false;
+                        mode = TM_TOP;
+                        continue;
+                    }
+                    p = sc.order[leaf_pos++];
+                }
+                const DPrim &pr = sc.prims[p];
+                const bool geom = pr.type == SH_MESH || pr.type == SH_CLOUD;
+                if (leaf_box || (FAST && (geom || PT_ANY))) {
+                    /* FAST: the fast tree's leaf boxes are wider than the primitive's bounds, which are what the reference's walk tests
+                     * before it asks a primitive (its leaves hold one primitive each): that test comes now.  (Closest hit on an
+                     * analytic primitive: after the hit, below - a rectangle can report a hit in front of its own bounds.) */
+                    float te;
+                    if (COUNT) rn += 1;
+                    if (!slab_test6(pr.bmin[0], pr.bmin[1], pr.bmin[2], pr.bmax[0], pr.bmax[1], pr.bmax[2], ro, inv, tmax, &te)) continue;
+                }
+                if (geom) {
+                    cp = p;
+                    node = pr.root;
+                    PT_PUSH(GEOM_BOTTOM); /* under the mesh's entries: popping it leaves the mesh */
+                    mode = TM_GEOM;
+                } else {
+                    float t;
+                    int face;
+                    if (COUNT) ri += 1;
+#ifdef PT_STATS
+                    const long long cp0_ = clock64();
+                    PS_WAVE_IT(PS_TOPPRIM_IT, PS_TOPPRIM_LANES);
+#endif
+                    const bool ph_ = shape_hit_t(sc, pr, ro, rd, tmax, &t, &face);
+#ifdef PT_STATS
+                    st_[PS_CYC_TOPPRIM] += clock64() - cp0_;
+#endif
+                    if (ph_) {
+                        if (PT_FZ_CLOSEST) {
+                            float te = 0;
+                            /* a ray that misses the bounds altogether never reaches this primitive in the reference: no candidate */
+                            if (!slab_test6(pr.bmin[0], pr.bmin[1], pr.bmin[2], pr.bmax[0], pr.bmax[1], pr.bmax[2], ro, inv, kInfinity, &te)) continue;
+                            const float g = fmaxr(te, t * FZ_WIDEN);
+                            /* a hit the reference would only take with a larger tMax than the bound of this walk (te > tmax), a hit
+                             * behind the best one, a best one inside the new bound: a second candidate */
+                            if (!(te <= tmax) || !(g >= t) || (hit && (t > tbest || tbest < g))) {
+                                PT_DEFER();
+                                break;
+                            }
+                            tbest = t;
+                            tmax = g;
+                        } else tmax = t;
+                        hp = p; hf = face; if (Source::BARY) { hb0 = 0; hb1 = 0; } hit = true;
+                        if (PT_ANY) { PT_FINISH(); break; }
                     }
                 }
             }
@@ -433,8 +554,8 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *s
             }
 #endif
             if (nh == 0) {
-                if (sp == sp_base) mode = TM_TOPLEAF;
-                else node = PT_POP();
+                node = PT_POP();
+                if (node == GEOM_BOTTOM) PT_LEAVE_GEOM();
             } else {
                 if (sp + 3 <= LDS_STACK) { /* the usual case: three unconditional LDS stores, farthest child deepest */
                     lds[sp * TRACE_TPB] = nh == 4 ? r3 : (nh == 3 ? r2 : r1);
@@ -457,7 +578,14 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *s
             PS_WAVE_IT(PS_LEAF_ENTRY, PS_LEAF_ENTRY_LANES);
             unsigned packed = (unsigned)(-(node + 1));
             unsigned first = packed & 0x07FFFFFFu, n = (packed >> 27) + 1;
-            bool ended = false;
+            bool ended = false, deferred = false;
+            /* FAST closest hit: the first item accepted after a hit on ANOTHER primitive is a second candidate (inside one
+             * primitive the walk is the reference's own, whatever tree led here) */
+#define PT_FZ_ACCEPT_ITEM(t_)                                                                             \
+    if (PT_FZ_CLOSEST) {                                                                                  \
+        if (hit && hp != cp && ((t_) > tbest || tbest < (t_) * FZ_WIDEN)) { deferred = true; break; }     \
+        tbest = (t_);                                                                                     \
+    }
             for (unsigned i = 0; i < n; i++) {
                 PS_WAVE_IT(PS_LEAF_IT, PS_LEAF_LANES);
                 const float4 *ip = reinterpret_cast<const float4 *>(sc.items + first + i);
@@ -467,7 +595,8 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *s
                 if (kind == ITEM_TRI) {
                     float t, b0, b1, b2;
                     if (tri_hit_pre(ro, tr, tmax, f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), &t, &b0, &b1, &b2)) {
-                        tmax = t; hp = cp; hf = __float_as_int(q1.w); hb0 = b0; hb1 = b1; hit = true;
+                        PT_FZ_ACCEPT_ITEM(t)
+                        tmax = t; hp = cp; hf = __float_as_int(q1.w); if (Source::BARY) { hb0 = b0; hb1 = b1; } hit = true;
                         if (PT_ANY) { ended = true; break; }
                     }
                 } else {
@@ -475,14 +604,19 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *s
                     particle_object_ray(ro, rd, f3(q0.x, q0.y, q0.z), &o, &dd);
                     float t;
                     if (particle_box_test(ro, inv, tmax, f3(q0.x, q0.y, q0.z), q1.x) && sphere_hit_t_obj(o, dd, q1.x, tmax, &t)) {
-                        tmax = t; hp = cp; hf = __float_as_int(q1.w); hb0 = 0; hb1 = 0; hit = true;
+                        PT_FZ_ACCEPT_ITEM(t)
+                        tmax = t; hp = cp; hf = __float_as_int(q1.w); if (Source::BARY) { hb0 = 0; hb1 = 0; } hit = true;
                         if (PT_ANY) { ended = true; break; }
                     }
                 }
             }
-            if (ended) PT_FINISH();
-            else if (sp == sp_base) mode = TM_TOPLEAF;
-            else node = PT_POP();
+#undef PT_FZ_ACCEPT_ITEM
+            if (deferred) PT_DEFER();
+            else if (ended) PT_FINISH();
+            else {
+                node = PT_POP();
+                if (node == GEOM_BOTTOM) PT_LEAVE_GEOM();
+            }
         }
 #ifdef PT_STATS
         const long long c4_ = clock64();
@@ -501,6 +635,9 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *s
 #endif
 #undef PT_FINISH
 #undef PT_ANY
+#undef PT_FZ_CLOSEST
+#undef PT_DEFER
+#undef PT_LEAVE_GEOM
 }
 
 /* ---- fullest-phase-first scheduling -------------------------------------------------------------------
@@ -777,12 +914,13 @@ PD void persistent_trace_sched(const DScene &sc, Source src, int *lds, const flo
 #ifndef PT_SCHED
 #define PT_SCHED 0 /* r02 on config[1]: phases in sequence 190.5 ms per 32-spp pass, fullest-phase-first 193.2 */
 #endif
-template <class Source, bool COUNT>
+template <class Source, bool COUNT, bool FAST = false>
 PD void persistent_trace_any(const DScene &sc, Source src, int *lds, const float4 *staged, const float4 *top_staged, unsigned *total_nodes,
                              unsigned *total_items) {
 #if PT_SCHED
+    static_assert(!FAST || !PT_SCHED, "the fullest-phase-first variant walks the reference's tree only");
     persistent_trace_sched<Source, COUNT>(sc, src, lds, staged, total_nodes, total_items);
 #else
-    persistent_trace<Source, COUNT>(sc, src, lds, staged, top_staged, total_nodes, total_items);
+    persistent_trace<Source, COUNT, FAST>(sc, src, lds, staged, top_staged, total_nodes, total_items);
 #endif
 }

@@ -443,6 +443,133 @@ int build_top(std::vector<TopNode> &nodes, std::vector<int32_t> &order, TopHandl
     nodes[me] = nd;
     return me;
 }
+/* ---- a second tree over the same primitives, built for speed (round 3) ------------------------------------------
+ * The reference's tree splits at the median along axes drawn from rand(): in a room of a hundred primitives a ray steps through
+ * ~25 of its nodes.  Most rays do not need its order: an any-hit ray's answer cannot depend on the order at all (its tMax never
+ * changes before the walk ends), and a closest-hit ray's answer is the candidate of smallest t unless the reference would have
+ * culled it or two candidates lie within rounding of each other - which the tracer detects, and then walks the reference's tree
+ * (dev_trace.h "fast top level").  This tree is a plain full-sweep SAH binary tree, one primitive per leaf, over boxes that hold
+ * every hit point a primitive can report: the shape's bounds, for a rectangle also the slab its test really uses
+ * (rectangle.cpp:8 vs :37-40: thicker than its bounds), grown by a margin far above rounding. */
+struct FastHandle {
+    float mn[3], mx[3], c[3];
+    int32_t prim;
+};
+inline float box_area(const float *mn, const float *mx) {
+    const float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+    return 2.f * (dx * dy + dy * dz + dz * dx);
+}
+int build_fast_top(std::vector<TopNode> &nodes, std::vector<int32_t> &order, FastHandle *h, int n) {
+    const int me = (int)nodes.size();
+    nodes.emplace_back();
+    TopNode nd;
+    memset(&nd, 0, sizeof(nd));
+    for (int a = 0; a < 3; a++) { nd.bmin[a] = h[0].mn[a]; nd.bmax[a] = h[0].mx[a]; }
+    for (int i = 1; i < n; i++)
+        for (int a = 0; a < 3; a++) {
+            if (h[i].mn[a] < nd.bmin[a]) nd.bmin[a] = h[i].mn[a];
+            if (h[i].mx[a] > nd.bmax[a]) nd.bmax[a] = h[i].mx[a];
+        }
+    if (n == 1) {
+        nd.left = nd.right = -1;
+        nd.first = (int32_t)order.size();
+        nd.n = 1;
+        order.push_back(h[0].prim);
+        nodes[me] = nd;
+        return me;
+    }
+    /* full sweep along each axis over the handles sorted by box centre: cost = area(L) * |L| + area(R) * |R| */
+    int best_axis = 0, best_k = n / 2;
+    float best_cost = FLT_MAX;
+    std::vector<float> right_area(n);
+    for (int axis = 0; axis < 3; axis++) {
+        std::stable_sort(h, h + n, [axis](const FastHandle &a, const FastHandle &b) { return a.c[axis] < b.c[axis]; });
+        float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        for (int i = n - 1; i >= 1; i--) {
+            for (int a = 0; a < 3; a++) { mn[a] = std::min(mn[a], h[i].mn[a]); mx[a] = std::max(mx[a], h[i].mx[a]); }
+            right_area[i] = box_area(mn, mx);
+        }
+        for (int a = 0; a < 3; a++) { mn[a] = FLT_MAX; mx[a] = -FLT_MAX; }
+        for (int k = 1; k < n; k++) { /* left = [0, k), right = [k, n) */
+            for (int a = 0; a < 3; a++) { mn[a] = std::min(mn[a], h[k - 1].mn[a]); mx[a] = std::max(mx[a], h[k - 1].mx[a]); }
+            const float cost = box_area(mn, mx) * k + right_area[k] * (n - k);
+            if (cost < best_cost) { best_cost = cost; best_axis = axis; best_k = k; }
+        }
+    }
+    std::stable_sort(h, h + n, [best_axis](const FastHandle &a, const FastHandle &b) { return a.c[best_axis] < b.c[best_axis]; });
+    const int l = build_fast_top(nodes, order, h, best_k);
+    const int r = build_fast_top(nodes, order, h + best_k, n - best_k);
+    nd.left = l;
+    nd.right = r;
+    nodes[me] = nd;
+    return me;
+}
+/* the box of primitive `pr` in the fast tree; false: not finite (the scene then keeps the reference's tree only) */
+bool fast_top_box(const DPrim &pr, FastHandle *out) {
+    float mn[3], mx[3];
+    for (int a = 0; a < 3; a++) { mn[a] = pr.bmin[a]; mx[a] = pr.bmax[a]; }
+    if (pr.type == SH_RECT) { /* the eight corners of the slab of Rectangle::Intersect, in world space */
+        const float hx = pr.p[0] / 2, hy = pr.p[1] / 2, zb = 0.0001f * std::max(hx, hy);
+        for (int k = 0; k < 8; k++) {
+            const float x = (k & 1) ? hx : -hx, y = (k & 2) ? hy : -hy, z = (k & 4) ? zb : -zb;
+            for (int a = 0; a < 3; a++) {
+                const float w = pr.o2w[4 * a] * x + pr.o2w[4 * a + 1] * y + pr.o2w[4 * a + 2] * z + pr.o2w[4 * a + 3];
+                mn[a] = std::min(mn[a], w);
+                mx[a] = std::max(mx[a], w);
+            }
+        }
+    }
+    float ext = 0, mag = 0;
+    for (int a = 0; a < 3; a++) {
+        if (!std::isfinite(mn[a]) || !std::isfinite(mx[a]) || mn[a] > mx[a]) return false;
+        ext = std::max(ext, mx[a] - mn[a]);
+        mag = std::max(mag, std::max(std::fabs(mn[a]), std::fabs(mx[a])));
+    }
+    const float margin = 1e-4f * ext + 1e-5f * mag + 1e-6f;
+    if (!std::isfinite(margin)) return false;
+    for (int a = 0; a < 3; a++) {
+        out->mn[a] = mn[a] - margin;
+        out->mx[a] = mx[a] + margin;
+        out->c[a] = 0.5f * mn[a] + 0.5f * mx[a];
+        if (!std::isfinite(out->mn[a]) || !std::isfinite(out->mx[a])) return false;
+    }
+    return true;
+}
+/* Numbers the nodes of `tree` breadth first - inner nodes first, then the leaves, so that the LDS copy of the first TOP_LDS_NODES
+ * holds only nodes the persistent tracer reads - and gives every inner node copies of its children's boxes and, for a child that
+ * is a one-primitive leaf, that primitive (TopNode::pad: the tracer then goes from the parent straight to the primitive).  Child
+ * indices are offset by `base`, the place of the tree's root in the scene's node array; `order` = the tree's leaf handles. */
+void finish_top_tree(std::vector<TopNode> &tree, const std::vector<int32_t> &order, int32_t base) {
+    if (tree.empty()) return;
+    const size_t nt = tree.size();
+    std::vector<int32_t> bfs{0}, new_of(nt, -1);
+    for (size_t head = 0; head < bfs.size(); head++) {
+        const TopNode &nd = tree[bfs[head]];
+        if (nd.left >= 0) { bfs.push_back(nd.left); bfs.push_back(nd.right); }
+    }
+    int32_t next = 0;
+    if (tree[0].left < 0) new_of[0] = next++; /* a tree of one leaf: the root stays node 0 */
+    for (size_t k = 0; k < bfs.size(); k++)
+        if (tree[bfs[k]].left >= 0) new_of[bfs[k]] = next++;
+    for (size_t k = 0; k < bfs.size(); k++)
+        if (new_of[bfs[k]] < 0) new_of[bfs[k]] = next++;
+    std::vector<TopNode> moved(nt);
+    for (size_t i = 0; i < nt; i++) {
+        TopNode nd = tree[i];
+        nd.pad[0] = nd.pad[1] = -1;
+        if (nd.left >= 0) {
+            const TopNode &l = tree[nd.left], &r = tree[nd.right];
+            for (int a = 0; a < 3; a++) { nd.lmin[a] = l.bmin[a]; nd.lmax[a] = l.bmax[a]; nd.rmin[a] = r.bmin[a]; nd.rmax[a] = r.bmax[a]; }
+            if (l.left < 0 && l.n == 1) nd.pad[0] = order[l.first];
+            if (r.left < 0 && r.n == 1) nd.pad[1] = order[r.first];
+            nd.left = base + new_of[nd.left];
+            nd.right = base + new_of[nd.right];
+        }
+        moved[new_of[i]] = nd;
+    }
+    tree.swap(moved);
+}
+
 /* the rand() draws of one _CreateBVH over n handles: one per node */
 void burn_bvh_rand(int n, int depth, int max_depth) {
     if (n <= 0) return;
@@ -933,26 +1060,30 @@ int ptr_flatten(const PtrFlatScene *fs, HostScene *hs, std::string *err) {
         if (!th.empty()) build_top(hs->top, hs->order, th.data(), (int)th.size(), 0, 20, -1);
         /* The walk only follows left / right / first: renumber the nodes breadth first (the upper levels, which every ray
          * steps through, become top[0 .. TOP_LDS_NODES)) and give every inner node copies of its children's boxes. */
-        if (!hs->top.empty()) {
-            const size_t nt = hs->top.size();
-            std::vector<int32_t> bfs{0}, new_of(nt, -1);
-            for (size_t head = 0; head < bfs.size(); head++) {
-                const TopNode &nd = hs->top[bfs[head]];
-                if (nd.left >= 0) { bfs.push_back(nd.left); bfs.push_back(nd.right); }
+        finish_top_tree(hs->top, hs->order, 0);
+        hs->top_ref_nodes = (int)hs->top.size();
+        /* ... and behind it the tree most rays walk instead (build_fast_top above; PTR_TOP_TREE=ref: the reference's tree only).
+         * Worth it from a handful of primitives on: with two or three the trees are the same. */
+        const char *tt = getenv("PTR_TOP_TREE");
+        const bool want_fast = !(tt && !strcmp(tt, "ref")) && hs->prims.size() >= 4;
+        if (want_fast) {
+            std::vector<FastHandle> fh(hs->prims.size());
+            bool ok = true;
+            for (size_t i = 0; i < hs->prims.size() && ok; i++) {
+                ok = fast_top_box(hs->prims[i], &fh[i]);
+                fh[i].prim = (int32_t)i;
             }
-            for (size_t k = 0; k < bfs.size(); k++) new_of[bfs[k]] = (int32_t)k;
-            std::vector<TopNode> moved(nt);
-            for (size_t i = 0; i < nt; i++) {
-                TopNode nd = hs->top[i];
-                if (nd.left >= 0) {
-                    const TopNode &l = hs->top[nd.left], &r = hs->top[nd.right];
-                    for (int a = 0; a < 3; a++) { nd.lmin[a] = l.bmin[a]; nd.lmax[a] = l.bmax[a]; nd.rmin[a] = r.bmin[a]; nd.rmax[a] = r.bmax[a]; }
-                    nd.left = new_of[nd.left];
-                    nd.right = new_of[nd.right];
-                }
-                moved[new_of[i]] = nd;
+            if (ok) {
+                std::vector<TopNode> fast;
+                std::vector<int32_t> forder;
+                build_fast_top(fast, forder, fh.data(), (int)fh.size());
+                finish_top_tree(fast, forder, (int32_t)hs->top_ref_nodes);
+                const int32_t obase = (int32_t)hs->order.size();
+                for (TopNode &nd : fast)
+                    if (nd.left < 0) nd.first += obase;
+                hs->top.insert(hs->top.end(), fast.begin(), fast.end());
+                hs->order.insert(hs->order.end(), forder.begin(), forder.end());
             }
-            hs->top.swap(moved);
         }
     }
     return PTR_OK;

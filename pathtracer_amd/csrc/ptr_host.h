@@ -43,8 +43,9 @@ struct HostScene {
     std::vector<DToyTri> toy_tris;
     std::vector<float> tris;
     std::vector<int32_t> uvidx;
-    std::vector<TopNode> top;   /* the reference's BVH over primitives */
-    std::vector<int32_t> order; /* its leaf handles: primitive indices */
+    std::vector<TopNode> top;   /* the reference's BVH over primitives: top[0 .. top_ref_nodes); behind it the fast tree (ptr_build.cpp), if built */
+    std::vector<int32_t> order; /* their leaf handles: primitive indices */
+    int top_ref_nodes = 0;
     std::vector<float> env_texels, env_func, env_cdf, env_func_int, env_marg_cdf;
     float env_marg_int = 0;
     int env_w = 0, env_h = 0, env_nu = 0, env_nv = 0;

@@ -404,9 +404,9 @@ static int set_err(int code, const std::string &msg) {
         if (e_ != hipSuccess) return set_err(PTR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-enum { K_RAYGEN = 0, K_TRACE, K_SHADE, K_SHADOW, K_MIS, K_RESOLVE, K_FILM, K_FINISH, K_MISS, K_MIS_ANY, K_PROBE, K_API_TRACE = K_TRACE };
+enum { K_RAYGEN = 0, K_TRACE, K_SHADE, K_SHADOW, K_MIS, K_RESOLVE, K_FILM, K_FINISH, K_MISS, K_MIS_ANY, K_PROBE, K_FALLBACK, K_API_TRACE = K_TRACE };
 static const char *kKernelNames[PTR_PROF_KERNELS] = {"raygen", "trace_closest", "shade", "nee_shadow", "nee_mis", "nee_resolve", "film",
-                                                     "finish", "miss", "nee_mis_any", "sss_probe"};
+                                                     "finish", "miss", "nee_mis_any", "sss_probe", "trace_fallback"};
 
 struct ProfSpan {
     hipEvent_t a, b;
@@ -420,7 +420,8 @@ struct ProfSpan {
  * of one overlaps the bulk of the others. */
 #define N_LANES 6 /* passes in flight (each on its own stream, ~5 GB of buffers at 16 M slots): 4 -> 6 gave +3.5 %, 8 no more */
 #define MAX_ITERS 20
-#define LANE_COUNTER_INTS (10 * MAX_ITERS)
+#define LANE_COUNTER_INTS (14 * MAX_ITERS)
+#define LANE_FB_COUNTS (10 * MAX_ITERS) /* fallback launches (fast top level, dev_trace.h): per bounce {count, cursor} of the path segments, then of the MIS rays */
 /* BSSRDF probe chains as tracer rays (rt_shade.h): the lane's counters for them, per staged bounce: [0] deferred vertices,
  * [1] chains that got a record, [2] the ray-fetch cursor of the chain launch, [4..8) k_route's counters over the exit-point
  * records (unused, records, shadow rays, MIS rays), [8], [9] the fetch cursors of their rays */
@@ -434,6 +435,7 @@ struct Lane {
     int *counts = nullptr;      /* device: [MAX_ITERS][4] = next, nee, shadow, mis; [MAX_ITERS][3] ray-fetch cursors;
                                    [MAX_ITERS] live paths that did not end in the miss pre-pass; [MAX_ITERS][2] of them light / heavy to shade */
     int *counts_host = nullptr; /* pinned: the [MAX_ITERS][4] counts of the last finished pass */
+    int *fb_queue = nullptr;    /* closest-hit rays a fast-top-level launch leaves to the reference's tree (dev_trace.h): cap slots, used by one launch at a time */
     hipEvent_t film_done = nullptr, joined = nullptr;
     int staged_used = 0, slots_used = 0; /* of the pass last queued on this lane */
     /* probe-chain records (scenes with a BSSRDF material only; allocated at the first such pass) */
@@ -465,6 +467,11 @@ struct PtrContext {
     bool bin_hits = false;       /* PTR_BIN_HITS=1: k_miss compacts the vertices to shade into light and heavy materials (measured: no gain) */
     bool nee_one_launch = false; /* shadow + any-hit MIS rays of a bounce in one launch (PTR_NEE_ONE) */
     bool nee_closest_ok = true; /* PTR_NEE_CLOSEST=0: keep the in-kernel walks wherever a primitive has no material */
+    /* PTR_FAST_TOP=1: rays walk the fast top-level tree where the scene has one and their answer cannot depend on the reference's
+     * order (dev_trace.h).  Exact (films and hits bit-identical) but measured SLOWER, so off: the room of configs[2] tests 72.2 -> 62.0
+     * boxes per closest-hit ray in the SAH tree - a ray through a furnished room really does cross that many primitive bounds -
+     * while the checks cost the closest-hit tracer 18.3 -> 26.0 ms per launch (profiles/r03_fast_top_level.txt). */
+    bool fast_top = false;
     bool mis_any_hit = true; /* MIS rays as any-hit rays where the result cannot tell the difference (PTR_MIS_ANY=0: never) */
     int scene_max_lobes = MAX_LOBES;
     bool scene_has_sss = false; /* some material carries a BSSRDF: k_shade<true> / k_finish<true> */
@@ -502,9 +509,15 @@ struct PtrContext {
     int stage_div = 1024; /* a bounce is staged while more than slots / stage_div paths are alive (PTR_STAGE_DIV) */
     int spread = 1; /* a ptr_render call deals its samples to this many passes (lanes) */
     int *api_fetch = nullptr; /* ray-fetch cursors of the stand-alone trace entry points (rotating) */
+    int *api_fb = nullptr;    /* their fallback queue (fast top level): two counters, then api_fb_cap slots */
+    int api_fb_cap = 0;
     int *static_scratch = nullptr; /* this device's copy of scratch[] (ptr_trace_closest_noalloc) */
     int api_fetch_next = 0;
     int persist_blocks = 1024;
+    bool persist_blocks_forced = false;
+    int n_cus = 256;
+    int trace_waves_forced = 0; /* PTR_TRACE_WAVES=4|5: the tracer build for every scene */
+    int wide_from = 4;          /* analytic primitives from which a scene gets the 128-register build (PTR_TRACE_WIDE_FROM) */
     int nb_max = 1;
     unsigned long long *ctrs = nullptr;
     uint64_t camera_rays = 0;
@@ -554,7 +567,7 @@ static void free_film(PtrContext *ctx) {
     if (!ctx->staged_fixed) ctx->staged_bounces = 6; /* the feedback below belongs to the buffers that go away */
     for (Lane &l : ctx->lanes) {
         void *ptrs[] = {l.pipe.ro, l.pipe.rd, l.pipe.hprim, l.pipe.hface, l.pipe.ht, l.pipe.paths, l.pipe.nee,
-                        l.queues[0], l.queues[1], l.queues[2], l.queues[3], l.queues[4], l.queues[5], l.counts};
+                        l.queues[0], l.queues[1], l.queues[2], l.queues[3], l.queues[4], l.queues[5], l.counts, l.fb_queue};
         for (void *p : ptrs)
             if (p) (void)hipFree(p);
         if (l.counts_host) (void)hipHostFree(l.counts_host);
@@ -564,6 +577,7 @@ static void free_film(PtrContext *ctx) {
         for (int q = 0; q < 6; q++) l.queues[q] = nullptr;
         l.counts = nullptr;
         l.counts_host = nullptr;
+        l.fb_queue = nullptr;
         l.staged_used = 0;
         l.slots_used = 0;
     }
@@ -621,13 +635,35 @@ static inline unsigned trace_blocks(const PtrContext *ctx, long long n) {
 #define API_FETCH_SLOTS 256
 /* one launch of the persistent tracer; n_upper bounds the ray count for sizing the grid (the
  * count itself may be in device memory, io.n_ptr); io.counter must be zero when the kernel starts */
-static void launch_ptrace(PtrContext *ctx, hipStream_t s, const TraceIO &io, int n_upper, bool any, bool count, int family, long long n_est = -1) {
+/* fb_queue / fb_counters ({count, fetch cursor}, both zero): a closest-hit launch in a scene with a fast top-level tree walks that
+ * tree and leaves the rays whose answer may need the reference's order in fb_queue; a second launch over that queue walks the
+ * reference's tree (dev_trace.h).  Without them a closest-hit launch walks the reference's tree. */
+static void launch_ptrace(PtrContext *ctx, hipStream_t s, const TraceIO &io_in, int n_upper, bool any, bool count, int family, long long n_est = -1,
+                          int *fb_queue = nullptr, int *fb_counters = nullptr) {
     if (n_est < 0 || n_est > n_upper) n_est = n_upper; /* what picks the tracer: the expected ray count (n_upper only bounds it) */
     const bool quad = use_quad(ctx, n_est);
     unsigned blocks = trace_blocks(ctx, quad ? (n_est > 0 ? n_est : 1) : n_upper);
-    ProfScope ps(ctx, s, family, (uint64_t)(io.n_ptr ? 0 : io.n));
-    if (quad) rt_launch_qtrace(any, count, blocks, s, ctx->sc, io, ctx->ctrs);
-    else rt_launch_ptrace(any, count, blocks, s, ctx->sc, io, ctx->ctrs);
+    TraceIO io = io_in;
+    const bool two = !any && !quad && ctx->sc.top_fast != 0 && fb_queue && fb_counters;
+    io.fb_queue = two ? fb_queue : nullptr;
+    io.fb_count = two ? fb_counters : nullptr;
+    {
+        ProfScope ps(ctx, s, family, (uint64_t)(io.n_ptr ? 0 : io.n));
+        if (quad) rt_launch_qtrace(any, count, blocks, s, ctx->sc, io, ctx->ctrs);
+        else rt_launch_ptrace(any, count, blocks, s, ctx->sc, io, ctx->ctrs);
+    }
+    if (two) {
+        TraceIO io2 = io_in;
+        io2.queue = fb_queue;
+        io2.n_ptr = fb_counters;
+        io2.n = 0;
+        io2.counter = fb_counters + 1;
+        io2.fb_queue = nullptr;
+        io2.fb_count = nullptr;
+        io2.is_fallback = 1;
+        ProfScope ps(ctx, s, K_FALLBACK, 0);
+        rt_launch_ptrace(false, count, trace_blocks(ctx, n_upper / 8 + 1), s, ctx->sc, io2, ctx->ctrs);
+    }
 }
 static TraceIO soa_io(int n, const int *queue, long long plane, const float *o, const float *d, const float *tmax, int *prim, int *face,
                       float *t, float *b0, float *b1) {
@@ -645,7 +681,21 @@ static TraceIO soa_io(int n, const int *queue, long long plane, const float *o, 
 static int api_trace(PtrContext *ctx, TraceIO io, bool any) {
     io.counter = ctx->api_fetch + (ctx->api_fetch_next++ % API_FETCH_SLOTS);
     HIPCHK(hipMemsetAsync(io.counter, 0, sizeof(int), ctx->stream));
-    launch_ptrace(ctx, ctx->stream, io, io.n, any, !any && ctx->count_traversal, K_API_TRACE);
+    int *fbq = nullptr, *fbc = nullptr;
+    if (!any && ctx->sc.top_fast) { /* closest hit through the fast top-level tree: a fallback queue of n slots (grown when a batch needs more) */
+        if (ctx->api_fb_cap < io.n) {
+            HIPCHK(hipStreamSynchronize(ctx->stream)); /* an earlier batch may still be using the old one */
+            if (ctx->api_fb) (void)hipFree(ctx->api_fb);
+            ctx->api_fb = nullptr;
+            ctx->api_fb_cap = 0;
+            HIPCHK(hipMalloc((void **)&ctx->api_fb, ((size_t)io.n + 2) * sizeof(int)));
+            ctx->api_fb_cap = io.n;
+        }
+        fbc = ctx->api_fb; /* {count, cursor}, then the queue */
+        fbq = ctx->api_fb + 2;
+        HIPCHK(hipMemsetAsync(fbc, 0, 2 * sizeof(int), ctx->stream));
+    }
+    launch_ptrace(ctx, ctx->stream, io, io.n, any, !any && ctx->count_traversal, K_API_TRACE, -1, fbq, fbc);
     HIPCHK(hipGetLastError());
     return PTR_OK;
 }
@@ -908,7 +958,8 @@ static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int ste
         for (int k = 0; k < staged; k++) {
             int *q_next = l.queues[qi];
             const int *n_ptr = k == 0 ? nullptr : l.counts + 4 * (k - 1);
-            launch_ptrace(ctx, s, path_io(l, q_cur, n_ptr, slots, cursors + 3 * k), upper_at(k), false, ctx->count_traversal, K_TRACE, est[k][0]);
+            int *fbc = l.counts + LANE_FB_COUNTS + 4 * k; /* {count, cursor} for the path segments, then for the MIS rays */
+            launch_ptrace(ctx, s, path_io(l, q_cur, n_ptr, slots, cursors + 3 * k), upper_at(k), false, ctx->count_traversal, K_TRACE, est[k][0], l.fb_queue, fbc);
             STAGE_CHECK("trace");
             enqueue_shade(ctx, l, prm, n_ptr, slots, upper_at(k), q_cur, q_next, k);
             STAGE_CHECK("miss / shade / route");
@@ -937,12 +988,12 @@ static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int ste
                         ProfScope ps(ctx, s, K_MIS_ANY, 0);
                         rt_launch_ptrace2any(trace_blocks(ctx, 2ll * upper_at(k)), s, ctx->sc, mio, mio2);
                     } else {
-                        launch_ptrace(ctx, s, mio, upper_at(k), false, false, K_MIS, est[k][2]);
+                        launch_ptrace(ctx, s, mio, upper_at(k), false, false, K_MIS, est[k][2], l.fb_queue, fbc + 2);
                         launch_ptrace(ctx, s, mio2, upper_at(k), false, false, K_MIS);
                     }
                 } else {
                 launch_ptrace(ctx, s, shadow_io(l, l.queues[3], cnt + 2, cursors + 3 * k + 1, nee_closest), upper_at(k), !nee_closest, ctx->count_traversal, K_SHADOW, est[k][1]);
-                launch_ptrace(ctx, s, mio, upper_at(k), mis_any, ctx->count_traversal, mis_any ? K_MIS_ANY : K_MIS, est[k][2]);
+                launch_ptrace(ctx, s, mio, upper_at(k), mis_any, ctx->count_traversal, mis_any ? K_MIS_ANY : K_MIS, est[k][2], l.fb_queue, fbc + 2);
                 if (exit_records(ctx, l, integrator)) { /* (counting pass: a launch per ray kind) */
                     TraceIO mio2 = exit_io(l, k, true);
                     mio2.any_as_hit = mis_any ? 1 : 0;
@@ -1053,7 +1104,10 @@ int ptr_create(int device, PtrContext **out) {
         return set_err(PTR_ERR_HIP, "context setup failed (hipMalloc / stream / event)");
     }
     /* persistent grid: enough 256-thread blocks to fill every CU at the tracer's occupancy */
+    ctx->n_cus = prop.multiProcessorCount;
     ctx->persist_blocks = prop.multiProcessorCount * PT_WAVES;
+    if (const char *e = getenv("PTR_TRACE_WAVES")) { int v = atoi(e); if (v == PT_WAVES || v == PT_WAVES_WIDE) ctx->trace_waves_forced = v; }
+    if (const char *e = getenv("PTR_TRACE_WIDE_FROM")) { int v = atoi(e); if (v >= 0) ctx->wide_from = v; }
     if (const char *e = getenv("PTR_STAGED")) { /* tuning experiments: fixed number of staged bounces */
         int v = atoi(e);
         if (v > 0) { ctx->staged_bounces = v; ctx->staged_fixed = true; }
@@ -1066,6 +1120,7 @@ int ptr_create(int device, PtrContext **out) {
     if (const char *e = getenv("PTR_BIN_HITS")) ctx->bin_hits = atoi(e) != 0;
     if (const char *e = getenv("PTR_STAGE_DIV")) { int v = atoi(e); if (v > 0) ctx->stage_div = v; }
     if (const char *e = getenv("PTR_MIS_ANY")) ctx->mis_any_hit = atoi(e) != 0;
+    if (const char *e = getenv("PTR_FAST_TOP")) ctx->fast_top = atoi(e) != 0;
     if (const char *e = getenv("PTR_NEE_CLOSEST")) ctx->nee_closest_ok = atoi(e) != 0;
     if (const char *e = getenv("PTR_SSS_CHAINS")) ctx->sss_rounds = atoi(e) != 0 ? 1 : 0;
     if (const char *e = getenv("PTR_SSS_CAP_DIV")) { int v = atoi(e); if (v >= 1) ctx->sss_cap_div = v; }
@@ -1076,7 +1131,7 @@ int ptr_create(int device, PtrContext **out) {
     }
     if (const char *e = getenv("PTR_PERSIST_BLOCKS")) { /* tuning experiments */
         int v = atoi(e);
-        if (v > 0) ctx->persist_blocks = v;
+        if (v > 0) { ctx->persist_blocks = v; ctx->persist_blocks_forced = true; }
     }
     *out = ctx;
     return PTR_OK;
@@ -1098,6 +1153,7 @@ int ptr_destroy(PtrContext *ctx) {
     if (ctx->entry) (void)hipEventDestroy(ctx->entry);
     if (ctx->ctrs) (void)hipFree(ctx->ctrs);
     if (ctx->api_fetch) (void)hipFree(ctx->api_fetch);
+    if (ctx->api_fb) (void)hipFree(ctx->api_fb);
     delete ctx;
     return PTR_OK;
 }
@@ -1280,7 +1336,16 @@ int ptr_scene_upload_built(PtrContext *ctx, const PtrBuiltScene *built) {
     sc.env_w = hs.env_w; sc.env_h = hs.env_h; sc.env_nu = hs.env_nu; sc.env_nv = hs.env_nv;
     sc.n_prims = (int)hs.prims.size();
     sc.n_lights = (int)hs.lights.size();
-    sc.n_top = (int)hs.top.size();
+    sc.n_top = hs.top_ref_nodes;
+    sc.top_fast = (int)hs.top.size() > hs.top_ref_nodes && ctx->fast_top ? hs.top_ref_nodes : 0;
+    sc.n_top_fast = sc.top_fast ? (int)hs.top.size() - hs.top_ref_nodes : 0;
+    {
+        /* the tracer build: four waves per SIMD (128 registers) once the top level holds many analytic primitives (rt_trace.hip) */
+        int analytic = 0;
+        for (const DPrim &pr : hs.prims) analytic += pr.type != SH_MESH && pr.type != SH_CLOUD ? 1 : 0;
+        sc.trace_waves = ctx->trace_waves_forced ? ctx->trace_waves_forced : (analytic >= ctx->wide_from ? PT_WAVES_WIDE : PT_WAVES);
+        if (!ctx->persist_blocks_forced) ctx->persist_blocks = ctx->n_cus * sc.trace_waves;
+    }
     sc.n_nodes = (int)hs.nodes.size();
     sc.n_items = (int)hs.items.size();
     sc.view_medium = hs.view_medium;
@@ -1317,8 +1382,8 @@ int ptr_camera_set(PtrContext *ctx, const PtrCamera *cam) {
     return PTR_OK;
 }
 
-/* bytes of pass buffers per path slot and lane: ray 24 + hit 12 + PathRec + NeeRec + six queues */
-static size_t lane_bytes_per_slot() { return 24 + 12 + sizeof(PathRec) + sizeof(NeeRec) + 6 * sizeof(int); }
+/* bytes of pass buffers per path slot and lane: ray 24 + hit 12 + PathRec + NeeRec + six queues + the fallback queue */
+static size_t lane_bytes_per_slot() { return 24 + 12 + sizeof(PathRec) + sizeof(NeeRec) + 7 * sizeof(int); }
 /* the pass buffers of every lane for nb samples per pass; on failure everything allocated so far is freed */
 static hipError_t alloc_lanes(PtrContext *ctx, int npix, int nb) {
     const size_t cap = (size_t)npix * nb;
@@ -1334,6 +1399,7 @@ static hipError_t alloc_lanes(PtrContext *ctx, int npix, int nb) {
         TRY(hipMalloc((void **)&l.pipe.paths, sizeof(PathRec) * cap_tiles)); /* PATH_WORDS tiled planes */
         TRY(hipMalloc((void **)&l.pipe.nee, sizeof(NeeRec) * cap_tiles));     /* NEE_WORDS tiled planes */
         for (int q = 0; q < 6; q++) TRY(hipMalloc((void **)&l.queues[q], sizeof(int) * cap));
+        if (ctx->fast_top) TRY(hipMalloc((void **)&l.fb_queue, sizeof(int) * cap));
         TRY(hipMalloc((void **)&l.counts, LANE_COUNTER_INTS * sizeof(int)));
         TRY(hipHostMalloc((void **)&l.counts_host, 4 * MAX_ITERS * sizeof(int), hipHostMallocDefault));
         if (e == hipSuccess) {

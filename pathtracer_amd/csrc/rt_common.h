@@ -17,6 +17,7 @@ static_assert(TPB == LOBE_STRIDE, "the lobe columns in LDS are strided by the bl
 #ifndef PT_WAVES
 #define PT_WAVES 5 /* wavefronts per SIMD the persistent tracer is compiled for */
 #endif
+#define PT_WAVES_WIDE 4 /* ... and its second build, with 128 registers, for scenes with many analytic primitives (DScene::trace_waves) */
 
 struct Pipe {
     float *ro, *rd;      /* 3 planes of cap floats each */
@@ -103,7 +104,7 @@ __device__ __forceinline__ void queue_append(int *counter, int *queue, bool pred
 
 enum { C_TOTAL = 0, C_MISS, C_SURF, C_MED, C_LIGHT, C_ZERO, C_SHADOW, C_MIS, C_PROBE, C_CAMERA, C_NODES, C_PRIMS, C_COUNT };
 /* pipeline statistics kept in the same lines, behind the PtrCounters fields (ptr_pipeline_stats_read) */
-enum { CX_FINISH_PATHS = C_COUNT, CX_FINISH_NEE, CX_SHADED, CX_NEE_RECORDS, CX_ANY_NODES, CX_ANY_ITEMS, CX_ANY_RAYS, CX_END };
+enum { CX_FINISH_PATHS = C_COUNT, CX_FINISH_NEE, CX_SHADED, CX_NEE_RECORDS, CX_ANY_NODES, CX_ANY_ITEMS, CX_ANY_RAYS, CX_FAST_DEFERRED, CX_END };
 static_assert(CX_END <= CTR_STRIDE, "a counter copy holds every counter");
 
 /* grid-stride helper: every lane of a wavefront runs the same number of rounds, so the ballots of
@@ -186,6 +187,7 @@ void rt_launch_ptrace2any(unsigned blocks, hipStream_t s, const DScene &sc, cons
 void rt_launch_ptrace3(bool count, unsigned blocks, hipStream_t s, const DScene &sc, const TraceIO &path, const TraceIO &shadow, const TraceIO &mis,
                        unsigned long long *ctrs);
 void rt_launch_ptrace(bool any, bool count, unsigned blocks, hipStream_t s, const DScene &sc, const TraceIO &io, unsigned long long *ctrs); /* rt_trace.hip */
+bool rt_ptrace_is_fast(bool any, const DScene &sc, const TraceIO &io); /* would that launch walk the fast top-level tree? */
 /* the same three launches with four lanes per ray (dev_qtrace.h), rt_qtrace.hip */
 void rt_launch_qtrace2any(unsigned blocks, hipStream_t s, const DScene &sc, const TraceIO &a, const TraceIO &b);
 void rt_launch_qtrace3(bool count, unsigned blocks, hipStream_t s, const DScene &sc, const TraceIO &path, const TraceIO &shadow, const TraceIO &mis,

@@ -158,10 +158,11 @@ __global__ void __launch_bounds__(TPB)
     constexpr bool BEGIN = MODE == SSS_BEGIN;
     constexpr bool TAIL = MODE == SSS_INPLACE || MODE == SSS_TAIL || BEGIN; /* works on the deferred vertices of the queue, compacted per 1024 entries */
     __shared__ int s_stack[MODE == SSS_INPLACE ? LDS_STACK * TRACE_TPB : 1];
-    __shared__ float s_lobes_static[TAIL ? 1 : LOBE_LDS_WORDS]; /* 80 KB: the BSDF lobes of the block's 256 vertices (dev_bsdf.h) */
     __shared__ int s_list[TAIL ? SSS_CHUNK : 1];
     __shared__ int s_count, s_base;
-    float *s_lobes = TAIL ? s_dyn_lobes : s_lobes_static;
+    /* the BSDF lobes of the block's 256 vertices (dev_bsdf.h): dynamic LDS, 16 KB per lobe of the scene's widest material (80 KB
+     * for five lobes; a scene of one- and two-lobe materials leaves room for more blocks per CU) */
+    float *s_lobes = s_dyn_lobes;
     LaneStack ls;
     ls.lds = &s_stack[MODE == SSS_INPLACE ? threadIdx.x : 0];
     NeeCtr nctr;
@@ -249,12 +250,9 @@ __global__ void __launch_bounds__(TPB)
 }
 
 template <int MODE> static void rt_launch_shade_t(unsigned blocks, hipStream_t s, const ShadeArgs &a) {
-    size_t dyn = 0;
-    if (MODE == SSS_INPLACE || MODE == SSS_BEGIN || MODE == SSS_TAIL) {
-        int lobes = a.max_lobes < 1 ? 1 : (a.max_lobes > MAX_LOBES ? MAX_LOBES : a.max_lobes);
-        dyn = (size_t)lobes * LOBE_WORDS * LOBE_STRIDE * sizeof(float);
-        static DynLdsOnce once;
-        ensure_max_dynamic_lds(once, reinterpret_cast<const void *>(&k_shade<MODE>), (int)(MAX_LOBES * LOBE_WORDS * LOBE_STRIDE * sizeof(float)));
-    }
+    const int lobes = a.max_lobes < 1 ? 1 : (a.max_lobes > MAX_LOBES ? MAX_LOBES : a.max_lobes);
+    const size_t dyn = (size_t)lobes * LOBE_WORDS * LOBE_STRIDE * sizeof(float);
+    static DynLdsOnce once;
+    ensure_max_dynamic_lds(once, reinterpret_cast<const void *>(&k_shade<MODE>), (int)(MAX_LOBES * LOBE_WORDS * LOBE_STRIDE * sizeof(float)));
     hipLaunchKernelGGL(k_shade<MODE>, dim3(blocks), dim3(TPB), dyn, s, a.sc, a.pp, a.prm, a.n_ptr, a.n_host, a.queue, a.chains, a.walk, a.ctrs);
 }

@@ -13,36 +13,60 @@
 #else
 #define PT_STAGED_NODES(sc) const float4 *s_staged = nullptr
 #endif
-/* top[0 .. TOP_LDS_NODES): the upper levels of the top-level tree (the reference's own, dev_scene.h TopNode), copied to LDS
- * by every persistent block before its first ray.  PT_LDS_TOPLEVEL=0 compiles the copy out. */
+/* The upper levels of the top-level tree the kernel's rays walk - the fast tree (FAST kernels; dev_trace.h, DScene::top_fast) or
+ * the reference's own (dev_scene.h TopNode) - copied to LDS by every persistent block before its first ray:
+ * top[root .. root + TOP_LDS_NODES).  PT_LDS_TOPLEVEL=0 compiles the copy out. */
 #ifndef PT_LDS_TOPLEVEL
 #define PT_LDS_TOPLEVEL 1
 #endif
 #if PT_LDS_TOPLEVEL
-#define PT_STAGED_TOP(sc)                                                                         \
+#define PT_STAGED_TOP(sc, fast)                                                                   \
     __shared__ float4 s_top[TOP_LDS_NODES * TOP_LDS_ROW];                                         \
     {                                                                                             \
-        const int ns_ = sc.n_top < TOP_LDS_NODES ? sc.n_top : TOP_LDS_NODES;                      \
-        const float4 *src_ = reinterpret_cast<const float4 *>(sc.top);                            \
+        const int nt_ = (fast) ? sc.n_top_fast : sc.n_top;                                        \
+        const int ns_ = nt_ < TOP_LDS_NODES ? nt_ : TOP_LDS_NODES;                                \
+        const float4 *src_ = reinterpret_cast<const float4 *>(sc.top + ((fast) ? sc.top_fast : 0)); \
         for (int i_ = threadIdx.x; i_ < ns_ * 6; i_ += TRACE_TPB) s_top[(i_ / 6) * TOP_LDS_ROW + (i_ % 6)] = src_[i_]; \
         __syncthreads();                                                                          \
     }
 #else
-#define PT_STAGED_TOP(sc) const float4 *s_top = nullptr
+#define PT_STAGED_TOP(sc, fast) const float4 *s_top = nullptr
 #endif
-template <bool ANY, bool COUNT>
-__global__ void __launch_bounds__(TRACE_TPB) __attribute__((amdgpu_waves_per_eu(PT_WAVES, PT_WAVES))) k_ptrace(DScene sc, TraceIO io, unsigned long long *ctrs) {
+/* WAVES: wavefronts per SIMD the kernel is compiled for.  Five (96 registers) where a ray spends its time in the meshes; four
+ * (128 registers) for scenes with many analytic primitives, whose tests - SDF marching, double-precision quadratics - spill at 96
+ * (DScene::trace_waves, ptr_runtime.hip; configs[2]: 22.5 against 16.4 ms per closest-hit launch, configs[1]: 6.77 against 6.80). */
+template <bool ANY, bool COUNT, bool FAST, int WAVES>
+__global__ void __launch_bounds__(TRACE_TPB) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) k_ptrace(DScene sc, TraceIO io, unsigned long long *ctrs) {
     __shared__ int s_stack[LDS_STACK * TRACE_TPB];
     PT_STAGED_NODES(sc);
-    PT_STAGED_TOP(sc);
+    PT_STAGED_TOP(sc, FAST);
     unsigned tn = 0, ti = 0;
     OneSource<ANY> src;
     src.io = io;
-    persistent_trace_any<OneSource<ANY>, COUNT>(sc, src, &s_stack[threadIdx.x], s_staged, s_top, &tn, &ti);
+    persistent_trace_any<OneSource<ANY>, COUNT, FAST>(sc, src, &s_stack[threadIdx.x], s_staged, s_top, &tn, &ti);
+    if (!ANY && !FAST && io.is_fallback && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctrs[CX_FAST_DEFERRED], (unsigned long long)(io.n_ptr ? *io.n_ptr : io.n));
     if (COUNT) { /* any-hit launches are counted apart: their rays end at the first hit and cost a fraction of a closest-hit ray */
         ctr_flush(ctrs, ANY ? CX_ANY_NODES : C_NODES, tn);
         ctr_flush(ctrs, ANY ? CX_ANY_ITEMS : C_PRIMS, ti);
         if (ANY && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctrs[CX_ANY_RAYS], (unsigned long long)(io.n_ptr ? *io.n_ptr : io.n));
+    }
+}
+
+/* closest hit with barycentrics stored (the stand-alone ptr_trace_closest): the two registers they live in are the pipeline's
+ * launches' to spare */
+template <bool COUNT, bool FAST, int WAVES>
+__global__ void __launch_bounds__(TRACE_TPB) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) k_ptrace_bary(DScene sc, TraceIO io, unsigned long long *ctrs) {
+    __shared__ int s_stack[LDS_STACK * TRACE_TPB];
+    PT_STAGED_NODES(sc);
+    PT_STAGED_TOP(sc, FAST);
+    unsigned tn = 0, ti = 0;
+    OneSource<false, true> src;
+    src.io = io;
+    persistent_trace_any<OneSource<false, true>, COUNT, FAST>(sc, src, &s_stack[threadIdx.x], s_staged, s_top, &tn, &ti);
+    if (!FAST && io.is_fallback && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctrs[CX_FAST_DEFERRED], (unsigned long long)(io.n_ptr ? *io.n_ptr : io.n));
+    if (COUNT) {
+        ctr_flush(ctrs, C_NODES, tn);
+        ctr_flush(ctrs, C_PRIMS, ti);
     }
 }
 
@@ -52,7 +76,7 @@ __global__ void __launch_bounds__(TRACE_TPB) __attribute__((amdgpu_waves_per_eu(
 k_ptrace3(DScene sc, TraceIO path, TraceIO shadow, TraceIO mis, unsigned long long *ctrs) {
     __shared__ int s_stack[LDS_STACK * TRACE_TPB];
     PT_STAGED_NODES(sc);
-    PT_STAGED_TOP(sc);
+    PT_STAGED_TOP(sc, false);
     unsigned tn = 0, ti = 0;
     ThreeSources src;
     src.path = path;
@@ -65,18 +89,26 @@ k_ptrace3(DScene sc, TraceIO path, TraceIO shadow, TraceIO mis, unsigned long lo
     }
 }
 
-__global__ void __launch_bounds__(TRACE_TPB) __attribute__((amdgpu_waves_per_eu(PT_WAVES, PT_WAVES))) k_ptrace2any(DScene sc, TraceIO a, TraceIO b) {
+template <bool FAST, int WAVES>
+__global__ void __launch_bounds__(TRACE_TPB) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) k_ptrace2any(DScene sc, TraceIO a, TraceIO b) {
     __shared__ int s_stack[LDS_STACK * TRACE_TPB];
     PT_STAGED_NODES(sc);
-    PT_STAGED_TOP(sc);
+    PT_STAGED_TOP(sc, FAST);
     unsigned tn = 0, ti = 0;
     TwoAny src;
     src.a = a;
     src.b = b;
-    persistent_trace_any<TwoAny, false>(sc, src, &s_stack[threadIdx.x], s_staged, s_top, &tn, &ti);
+    persistent_trace_any<TwoAny, false, FAST>(sc, src, &s_stack[threadIdx.x], s_staged, s_top, &tn, &ti);
 }
 void rt_launch_ptrace2any(unsigned blocks, hipStream_t s, const DScene &sc, const TraceIO &a, const TraceIO &b) {
-    hipLaunchKernelGGL(k_ptrace2any, dim3(blocks), dim3(TRACE_TPB), 0, s, sc, a, b);
+    const bool w4 = sc.trace_waves == PT_WAVES_WIDE;
+    if (sc.top_fast) { /* any hit: every ray may walk the fast tree */
+        if (w4) hipLaunchKernelGGL((k_ptrace2any<true, PT_WAVES_WIDE>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, a, b);
+        else hipLaunchKernelGGL((k_ptrace2any<true, PT_WAVES>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, a, b);
+    } else {
+        if (w4) hipLaunchKernelGGL((k_ptrace2any<false, PT_WAVES_WIDE>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, a, b);
+        else hipLaunchKernelGGL((k_ptrace2any<false, PT_WAVES>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, a, b);
+    }
 }
 
 /* The BSSRDF probe chains (dev_bssrdf.h): the persistent tracer with a source that continues - every chain is traced segment by
@@ -89,7 +121,7 @@ __global__ void __launch_bounds__(TRACE_TPB) __attribute__((amdgpu_waves_per_eu(
 k_pchain(DScene sc, uint32_t *planes, const int *n_ptr, int *cursor, unsigned long long *ctrs) {
     __shared__ int s_stack[LDS_STACK * TRACE_TPB];
     PT_STAGED_NODES(sc);
-    PT_STAGED_TOP(sc);
+    PT_STAGED_TOP(sc, false);
     unsigned tn = 0, ti = 0, probes = 0;
     ChainSource src;
     src.planes = planes;
@@ -109,11 +141,39 @@ void rt_launch_ptrace3(bool count, unsigned blocks, hipStream_t s, const DScene 
     else hipLaunchKernelGGL((k_ptrace3<false>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, path, shadow, mis, ctrs);
 }
 
+/* Any-hit rays walk the fast top-level tree whenever the scene has one; closest-hit rays when the launch also brings a fallback
+ * queue for the rays whose answer may need the reference's order (dev_trace.h): the caller then launches again over that queue,
+ * with io.fb_queue = null. */
+bool rt_ptrace_is_fast(bool any, const DScene &sc, const TraceIO &io) { return sc.top_fast != 0 && (any || (io.fb_queue && io.fb_count)); }
 void rt_launch_ptrace(bool any, bool count, unsigned blocks, hipStream_t s, const DScene &sc, const TraceIO &io, unsigned long long *ctrs) {
-    if (any && count) hipLaunchKernelGGL((k_ptrace<true, true>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, io, ctrs);
-    else if (any) hipLaunchKernelGGL((k_ptrace<true, false>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, io, ctrs);
-    else if (count) hipLaunchKernelGGL((k_ptrace<false, true>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, io, ctrs);
-    else hipLaunchKernelGGL((k_ptrace<false, false>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, io, ctrs);
+    const bool fast = rt_ptrace_is_fast(any, sc, io);
+    const bool w4 = sc.trace_waves == PT_WAVES_WIDE;
+#define PT_LAUNCH(A, C, F)                                                                                                     \
+    do {                                                                                                                       \
+        if (w4) hipLaunchKernelGGL((k_ptrace<A, C, F, PT_WAVES_WIDE>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, io, ctrs);     \
+        else hipLaunchKernelGGL((k_ptrace<A, C, F, PT_WAVES>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, io, ctrs);             \
+    } while (0)
+#define PT_LAUNCH_BARY(C, F)                                                                                                   \
+    do {                                                                                                                       \
+        if (w4) hipLaunchKernelGGL((k_ptrace_bary<C, F, PT_WAVES_WIDE>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, io, ctrs);   \
+        else hipLaunchKernelGGL((k_ptrace_bary<C, F, PT_WAVES>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, io, ctrs);           \
+    } while (0)
+    if (!any && !io.tile_words && (io.b0 || io.b1)) {
+        if (fast) { if (count) PT_LAUNCH_BARY(true, true); else PT_LAUNCH_BARY(false, true); }
+        else { if (count) PT_LAUNCH_BARY(true, false); else PT_LAUNCH_BARY(false, false); }
+    } else if (fast) {
+        if (any && count) PT_LAUNCH(true, true, true);
+        else if (any) PT_LAUNCH(true, false, true);
+        else if (count) PT_LAUNCH(false, true, true);
+        else PT_LAUNCH(false, false, true);
+    } else {
+        if (any && count) PT_LAUNCH(true, true, false);
+        else if (any) PT_LAUNCH(true, false, false);
+        else if (count) PT_LAUNCH(false, true, false);
+        else PT_LAUNCH(false, false, false);
+    }
+#undef PT_LAUNCH
+#undef PT_LAUNCH_BARY
 }
 
 #ifdef PT_STATS
