@@ -72,6 +72,9 @@ def measured_traffic(summary, kernel, config):
     if summary.get("_csrc_hash") != kernel_source_hash():
         return None  # counters of other kernel sources than this tree's: stale, not reported
     try:
+        if kernel not in summary:  # a prefix: the tracer's kernels carry further template arguments (fast top level, waves per SIMD)
+            names = [n for n in summary if n.startswith(kernel) and isinstance(summary[n], dict) and summary[n].get("counters")]
+            kernel = max(names, key=lambda n: summary[n].get("dispatches") or summary[n].get("calls") or 0)
         k = summary[kernel]
         c = k["counters"]
         n = max(1, int(k.get("dispatches") or k.get("calls") or 1))
@@ -294,7 +297,7 @@ def main():
         achieved = bytes_per_ray * rays_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         t_launches, t_ms = closest(prof)
         t_avg_ms = t_ms / max(1, t_launches)
-        traffic = measured_traffic(summary, "k_ptrace<false, false>", args.config)
+        traffic = measured_traffic(summary, "k_ptrace<false, false, false", args.config)
         # ---- the any-hit tracer k_ptrace<true,false> (shadow rays; MIS rays where any hit answers them): the largest kernel by
         # exclusive time on configs[1].  Same pricing, B = 52 (48 B ray in, 4 B answer out) + 32 per child box + 48 per item, with
         # its own per-ray counts from the counting pass (an any-hit ray ends at its first hit).
@@ -312,7 +315,7 @@ def main():
             a_ach = a_bytes * a_rays / (a_avg * 1e-3) / 1e9 if a_avg > 0 else 0.0
             roofline_any = {"bound": "hbm", "kernel": "k_ptrace<true,false> (persistent tracer, any hit: shadow rays + MIS rays that any hit answers)",
                             "achieved": a_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a_ach / HBM_PEAK_GBS,
-                            "traffic": measured_traffic(summary, "k_ptrace<true, false>", args.config), "traffic_unit": "bytes per launch",
+                            "traffic": measured_traffic(summary, "k_ptrace<true, false, false", args.config), "traffic_unit": "bytes per launch",
                             "bytes_per_ray": a_bytes, "nodes_per_ray": a_nodes, "items_per_ray": a_items, "avg_launch_ms": a_avg,
                             "rays_per_launch": a_rays, "launches": any_launches,
                             "note": "the direct-light rays the finish kernel traces inside itself are taken off (half of them per any-hit ray kind)"}

@@ -48,7 +48,7 @@ PD size_t plane_at(int W, int slot, int w) {
     return ((((size_t)(slot >> PLANE_TILE_SHIFT)) * W + w) << PLANE_TILE_SHIFT) | (size_t)(slot & ((1 << PLANE_TILE_SHIFT) - 1));
 }
 enum { PFL_SPECULAR = 1 };
-/* bits k_shade leaves in hprim[slot] for k_route (ptr_runtime.hip); bit q feeds queue q = counts[q] */
+/* bits k_shade leaves in Pipe::route for k_route (ptr_runtime.hip); bit q feeds queue q = counts[q] */
 enum { ROUTE_NEXT = 1, ROUTE_NEE = 2, ROUTE_SHADOW = 4, ROUTE_MIS = 8 };
 struct __attribute__((aligned(16))) PathRec {
     float L[3], beta[3];

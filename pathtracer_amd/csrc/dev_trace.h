@@ -38,6 +38,7 @@ struct TraceIO {
     int w_face1;    /* tiled planes, closest hit: 1 + the word that receives the face (0: the face is not stored) */
     /* fast top level (persistent_trace<.., FAST = true>): the closest-hit rays whose answer may need the reference's order are
      * left here - their slots, counted in *fb_count - for a second launch that walks the reference's tree */
+    int4 *hit16; /* closest hit: if set, the whole result of slot s goes to hit16[s] = (prim, face, t, 0) in one store (the pipeline's path segments) */
     int *fb_queue, *fb_count;
     int is_fallback; /* this IS that second launch (its ray count goes to the CX_FAST_DEFERRED statistic) */
 };
@@ -90,6 +91,10 @@ PD void trace_io_fetch(const TraceIO &io, int idx, int *slot, f3 *ro, f3 *rd, fl
 }
 template <bool COUNT>
 PD void trace_io_store(const TraceIO &io, bool any, int slot, bool hit, int hp, int hf, float tmax, float hb0, float hb1, unsigned rn, unsigned ri) {
+    if (io.hit16) {
+        io.hit16[slot] = make_int4(hit ? hp : -1, hit ? hf : -1, __float_as_int(tmax), 0);
+        return;
+    }
     if (io.tile_words) {
         int *b = reinterpret_cast<int *>(io.prim);
         b[plane_at(io.tile_words, slot, io.w_prim)] = (any && !io.any_as_hit) ? (hit ? 1 : 0) : (hit ? hp : -1);

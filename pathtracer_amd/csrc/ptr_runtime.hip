@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(TPB) k_miss(DScene sc, Pipe pp, PassParams prm
             int slot = 0;
             if (i < n) {
                 slot = queue ? queue[i] : (int)i;
-                const int hp = pp.hprim[slot];
+                const int hp = pp.hit[slot].x;
                 const int med = (int)pp.paths[plane_at(PATH_WORDS, slot, WORD_OF(PathRec, medium))];
                 keep = hp >= 0 || med >= 0;
                 if (cls && hp >= 0) {
@@ -236,7 +236,7 @@ __global__ void __launch_bounds__(TPB) k_route(const int *n_ptr, const int *queu
             if (i < n) {
                 slots[c] = queue ? queue[i] : (int)i;
                 recs[c] = by_place ? (int)i : slots[c];
-                bits[c] = route[slots[c]];
+                bits[c] = route[i]; /* (the route words are numbered like the queue's entries) */
             }
         }
         int mine = 0; /* lane q: entries this group adds to queue q */
@@ -566,7 +566,7 @@ static void free_film(PtrContext *ctx) {
     ctx->pix_map = nullptr;
     if (!ctx->staged_fixed) ctx->staged_bounces = 6; /* the feedback below belongs to the buffers that go away */
     for (Lane &l : ctx->lanes) {
-        void *ptrs[] = {l.pipe.ro, l.pipe.rd, l.pipe.hprim, l.pipe.hface, l.pipe.ht, l.pipe.paths, l.pipe.nee,
+        void *ptrs[] = {l.pipe.ro, l.pipe.rd, l.pipe.hit, l.pipe.route, l.pipe.paths, l.pipe.nee,
                         l.queues[0], l.queues[1], l.queues[2], l.queues[3], l.queues[4], l.queues[5], l.counts, l.fb_queue};
         for (void *p : ptrs)
             if (p) (void)hipFree(p);
@@ -705,7 +705,8 @@ static int api_trace(PtrContext *ctx, TraceIO io, bool any) {
  * be zero; n_ptr / n_host: number of live paths entering the bounce (device counter of the
  * previous bounce, or a host value); n_upper: an upper bound used only to size grids. */
 static TraceIO path_io(const Lane &l, const int *queue, const int *n_ptr, int n_host, int *cursor) {
-    TraceIO io = soa_io(n_host, queue, l.pipe.cap, l.pipe.ro, l.pipe.rd, nullptr, l.pipe.hprim, l.pipe.hface, l.pipe.ht, nullptr, nullptr);
+    TraceIO io = soa_io(n_host, queue, l.pipe.cap, l.pipe.ro, l.pipe.rd, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    io.hit16 = l.pipe.hit;
     io.n_ptr = n_ptr;
     io.counter = cursor;
     return io;
@@ -792,7 +793,7 @@ static void enqueue_shade(PtrContext *ctx, Lane &l, const PassParams &prm, const
         rt_launch_shade_sss(tail_blocks, s, a);
     } else rt_launch_shade(stride_blocks, s, a);
     hipLaunchKernelGGL(k_route, dim3(clampu(nblocks((n_upper + ROUTE_CHUNK - 1) / ROUTE_CHUNK), 32, 2048)), dim3(TPB), 0, s, (const int *)hit_count,
-                       (const int *)l.queues[5], (const int *)l.pipe.hprim, q_next, l.queues[2], l.queues[3], l.queues[4], cnt, 1);
+                       (const int *)l.queues[5], (const int *)l.pipe.route, q_next, l.queues[2], l.queues[3], l.queues[4], cnt, 1);
     if (a.chains.exit.planes) { /* the queues of the exit-point records, from the flags the tail kernel left per chain */
         int *scnt = l.sss_counts + SSS_COUNTER_STRIDE * cslot;
         const int upper = n_upper < l.sss_cap ? n_upper : l.sss_cap;
@@ -1273,8 +1274,6 @@ int ptr_scene_upload_built(PtrContext *ctx, const PtrBuiltScene *built) {
     if (rc) return rc;
     if (!built) return set_err(PTR_ERR_INVALID, "null built scene");
     const HostScene &hs = built->hs;
-    if (!hs.tables.empty() && hs.prims.size() >= (size_t)1 << 24)
-        return set_err(PTR_ERR_LIMIT, "a scene with a BSSRDF material may hold at most 2^24 primitives (the deferred vertices' hit word, rt_shade.h)");
     if ((rc = sync_all(ctx))) return rc;
     free_scene(ctx);
     DScene sc;
@@ -1382,8 +1381,8 @@ int ptr_camera_set(PtrContext *ctx, const PtrCamera *cam) {
     return PTR_OK;
 }
 
-/* bytes of pass buffers per path slot and lane: ray 24 + hit 12 + PathRec + NeeRec + six queues + the fallback queue */
-static size_t lane_bytes_per_slot() { return 24 + 12 + sizeof(PathRec) + sizeof(NeeRec) + 7 * sizeof(int); }
+/* bytes of pass buffers per path slot and lane: ray 24 + hit 16 + route 4 + PathRec + NeeRec + six queues + the fallback queue */
+static size_t lane_bytes_per_slot() { return 24 + 16 + 4 + sizeof(PathRec) + sizeof(NeeRec) + 7 * sizeof(int); }
 /* the pass buffers of every lane for nb samples per pass; on failure everything allocated so far is freed */
 static hipError_t alloc_lanes(PtrContext *ctx, int npix, int nb) {
     const size_t cap = (size_t)npix * nb;
@@ -1393,9 +1392,8 @@ static hipError_t alloc_lanes(PtrContext *ctx, int npix, int nb) {
     for (Lane &l : ctx->lanes) {
         TRY(hipMalloc((void **)&l.pipe.ro, 3 * sizeof(float) * cap));
         TRY(hipMalloc((void **)&l.pipe.rd, 3 * sizeof(float) * cap));
-        TRY(hipMalloc((void **)&l.pipe.hprim, sizeof(int) * cap));
-        TRY(hipMalloc((void **)&l.pipe.hface, sizeof(int) * cap));
-        TRY(hipMalloc((void **)&l.pipe.ht, sizeof(float) * cap));
+        TRY(hipMalloc((void **)&l.pipe.hit, sizeof(int4) * cap));
+        TRY(hipMalloc((void **)&l.pipe.route, sizeof(int) * cap));
         TRY(hipMalloc((void **)&l.pipe.paths, sizeof(PathRec) * cap_tiles)); /* PATH_WORDS tiled planes */
         TRY(hipMalloc((void **)&l.pipe.nee, sizeof(NeeRec) * cap_tiles));     /* NEE_WORDS tiled planes */
         for (int q = 0; q < 6; q++) TRY(hipMalloc((void **)&l.queues[q], sizeof(int) * cap));

@@ -21,8 +21,9 @@ static_assert(TPB == LOBE_STRIDE, "the lobe columns in LDS are strided by the bl
 
 struct Pipe {
     float *ro, *rd;      /* 3 planes of cap floats each */
-    int *hprim, *hface;
-    float *ht;
+    int4 *hit;  /* per path slot: (primitive or -1, face / item, t as bits, -) - one 16-byte store per ray of the tracer (round 3; three
+                 * scattered 4-byte stores before: a persistent lane finishes its ray alone, and each was a partial write of its own) */
+    int *route; /* per place in the bounce's queue of shaded vertices: where the vertex goes next (ROUTE_*, SHADE_DEFERRED), k_shade -> k_route */
     uint32_t *paths; /* PathRec as PATH_WORDS tiled planes (dev_nee.h: plane_at) */
     uint32_t *nee;   /* NeeRec as NEE_WORDS tiled planes */
     int cap;

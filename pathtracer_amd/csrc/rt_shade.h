@@ -13,7 +13,7 @@
  *
  *   k_shade<SSS_DEFER>    every vertex, exactly as k_shade<SSS_NONE> does - until a vertex samples the transmission lobe
  *                         of a BSSRDF material.  That vertex is dropped unfinished: nothing of it is stored (the direct-light
- *                         words it wrote are rewritten identically below), its hit word gets SHADE_DEFERRED.
+ *                         words it wrote are rewritten identically below), its route word gets SHADE_DEFERRED.
  *   k_shade<SSS_INPLACE>  only the deferred vertices, from the start (the RNG stream position is part of the path record, so
  *                         the replay draws the same numbers), now with the BSSRDF tail - probe segments, exit-point
  *                         direct light - traversed in place (dev_bssrdf.h).  A block takes 1024 queue entries at a time,
@@ -38,15 +38,14 @@
  * The chain's traversals - most of what the tail kernel used to spend its time on, at 3 waves/SIMD - run at the tracer's
  * occupancy, and a vertex's traversal count no longer serialises inside one lane. */
 extern __shared__ float s_dyn_lobes[];
-#define SHADE_DEFERRED (1 << 30) /* in the hit word of a vertex k_shade<SSS_DEFER> left to the tail kernel */
+#define SHADE_DEFERRED (1 << 30) /* in the route word of a vertex k_shade<SSS_DEFER> left to the tail kernels */
 #define SSS_CHUNK 1024
 
 /* where the chain number of a deferred vertex waits for the tail kernels: the tA word of its direct-light record, which only
  * the tracer's shadow launch writes, later in the bounce */
 #define SSS_CHAIN_WORD WORD_OF(NeeRec, tA)
-/* A deferred vertex's hit word: the primitive (scenes hold far fewer than 2^24), SHADE_DEFERRED, and in bits 24..27 the route
- * bits of its own direct-light record, which k_shade<SSS_DEFER> has already written */
-#define SHADE_PRIM_MASK 0x00FFFFFF
+/* A deferred vertex's route word: SHADE_DEFERRED, and in bits 24..27 the route bits of its own direct-light record, which
+ * k_shade<SSS_DEFER> has already written */
 #define SHADE_ROUTE_SHIFT 24
 
 /* The deferred vertices from where k_shade<SSS_DEFER> left them (dev_path.h sss_continue), MODE = SSS_BEGIN / SSS_TAIL /
@@ -54,8 +53,9 @@ extern __shared__ float s_dyn_lobes[];
 template <int MODE>
 __device__ __forceinline__ bool tail_slot(const DScene &sc, const Pipe &pp, const PassParams &prm, int slot, int rec_at, float *lobes, VertexCtr &ctr, SssCtx &sss) {
     const int cap = pp.cap;
-    const int word = pp.hprim[slot];
-    const int hit_prim = word & SHADE_PRIM_MASK, own_route = (word >> SHADE_ROUTE_SHIFT) & (ROUTE_NEE | ROUTE_SHADOW | ROUTE_MIS);
+    const int word = pp.route[rec_at];
+    const int4 h = pp.hit[slot];
+    const int hit_prim = h.x, own_route = (word >> SHADE_ROUTE_SHIFT) & (ROUTE_NEE | ROUTE_SHADOW | ROUTE_MIS);
     PathRec ps;
     soa_load<0, PATH_WORDS>(pp.paths, cap, slot, &ps);
     f3 ro(pp.ro[slot], pp.ro[cap + slot], pp.ro[2 * cap + slot]);
@@ -65,7 +65,7 @@ __device__ __forceinline__ bool tail_slot(const DScene &sc, const Pipe &pp, cons
     f3 beta = ld3(ps.beta);
     int med = ps.medium, bounces = ps.bounces, pflags = ps.flags;
     sss.slot = slot;
-    const TailOut to = sss_continue<MODE>(sc, prm.integrator, rng, ro, rd, med, hit_prim, pp.hface[slot], pp.ht[slot], beta, bounces, pflags, ctr, &sss, lobes);
+    const TailOut to = sss_continue<MODE>(sc, prm.integrator, rng, ro, rd, med, hit_prim, h.y, __int_as_float(h.z), beta, bounces, pflags, ctr, &sss, lobes);
     if (MODE == SSS_BEGIN) return true;
     if (!to.settled) return false;
     if (to.has_extra) { /* direct light at the exit point, resolved in this lane: it follows the vertex's own term in L */
@@ -92,14 +92,16 @@ __device__ __forceinline__ bool tail_slot(const DScene &sc, const Pipe &pp, cons
         pp.ro[slot] = ro.x; pp.ro[cap + slot] = ro.y; pp.ro[2 * cap + slot] = ro.z;
         pp.rd[slot] = rd.x; pp.rd[cap + slot] = rd.y; pp.rd[2 * cap + slot] = rd.z;
     }
-    pp.hprim[slot] = (to.alive ? ROUTE_NEXT : 0) | own_route;
+    pp.route[rec_at] = (to.alive ? ROUTE_NEXT : 0) | own_route;
     return true;
 }
 
 template <int MODE>
-__device__ __forceinline__ void shade_slot(const DScene &sc, const Pipe &pp, const PassParams &prm, int slot, int rec_at, int hit_prim, float *lobes, VertexCtr &ctr,
+__device__ __forceinline__ void shade_slot(const DScene &sc, const Pipe &pp, const PassParams &prm, int slot, int rec_at, float *lobes, VertexCtr &ctr,
                                            const SssCtx &sss, unsigned &shaded, unsigned &nee_recs SH_STATS_PARAM) {
     const int cap = pp.cap;
+    const int4 h = pp.hit[slot];
+    const int hit_prim = h.x;
     PathRec ps;
     soa_load<0, PATH_WORDS>(pp.paths, cap, slot, &ps);
 #ifdef SH_STATS
@@ -116,7 +118,7 @@ __device__ __forceinline__ void shade_slot(const DScene &sc, const Pipe &pp, con
     f3 L = ld3(ps.L), beta = ld3(ps.beta);
     int med = ps.medium, bounces = ps.bounces, pflags = ps.flags;
     SH_T(rec.st, SH_LOAD);
-    VertexOut vo = shade_vertex<MODE>(sc, prm.integrator, rng, ro, rd, med, hit_prim, pp.hface[slot], pp.ht[slot], L, beta, bounces, pflags, rec, ctr, &sss,
+    VertexOut vo = shade_vertex<MODE>(sc, prm.integrator, rng, ro, rd, med, hit_prim, h.y, __int_as_float(h.z), L, beta, bounces, pflags, rec, ctr, &sss,
                                       lobes);
     SH_T(rec.st, SH_TAIL);
     const bool alive = vo.alive, want_nee = vo.want_nee;
@@ -132,7 +134,7 @@ __device__ __forceinline__ void shade_slot(const DScene &sc, const Pipe &pp, con
         ps.flags = pflags;
         ps.dim = (int)rng.dim;
         soa_store<0, WORD_OF(PathRec, weight)>(pp.paths, cap, slot, &ps);
-        pp.hprim[slot] = hit_prim | SHADE_DEFERRED | (((want_nee ? ROUTE_NEE : 0) | (want_shadow ? ROUTE_SHADOW : 0) | (want_mis ? ROUTE_MIS : 0)) << SHADE_ROUTE_SHIFT);
+        pp.route[rec_at] = SHADE_DEFERRED | (((want_nee ? ROUTE_NEE : 0) | (want_shadow ? ROUTE_SHADOW : 0) | (want_mis ? ROUTE_MIS : 0)) << SHADE_ROUTE_SHIFT);
         return;
     }
     st3(ps.L, L);
@@ -146,9 +148,9 @@ __device__ __forceinline__ void shade_slot(const DScene &sc, const Pipe &pp, con
         pp.ro[slot] = ro.x; pp.ro[cap + slot] = ro.y; pp.ro[2 * cap + slot] = ro.z;
         pp.rd[slot] = rd.x; pp.rd[cap + slot] = rd.y; pp.rd[2 * cap + slot] = rd.z;
     }
-    /* where the vertex goes next is left in its (consumed) hit word; k_route turns these into the four queues.
+    /* where the vertex goes next is left in the route word of its place in the queue; k_route turns these into the four queues.
      * Appending here cost one atomic per wavefront and queue on a single cache line: a third of the kernel. */
-    pp.hprim[slot] = (alive ? ROUTE_NEXT : 0) | (want_nee ? ROUTE_NEE : 0) | (want_shadow ? ROUTE_SHADOW : 0) | (want_mis ? ROUTE_MIS : 0);
+    pp.route[rec_at] = (alive ? ROUTE_NEXT : 0) | (want_nee ? ROUTE_NEE : 0) | (want_shadow ? ROUTE_SHADOW : 0) | (want_mis ? ROUTE_MIS : 0);
 }
 
 template <int MODE>
@@ -182,8 +184,7 @@ __global__ void __launch_bounds__(TPB)
             if (threadIdx.x == 0) s_count = 0;
             __syncthreads();
             for (int j = threadIdx.x; j < SSS_CHUNK && base + j < n; j += TPB) {
-                const int slot = queue ? queue[base + j] : base + j;
-                if (pp.hprim[slot] & SHADE_DEFERRED) s_list[atomicAdd(&s_count, 1)] = base + j; /* the vertex's place in the queue = its direct-light record */
+                if (pp.route[base + j] & SHADE_DEFERRED) s_list[atomicAdd(&s_count, 1)] = base + j; /* the vertex's place in the queue = its direct-light record */
             }
             __syncthreads();
             const int cnt = s_count;
@@ -222,7 +223,7 @@ __global__ void __launch_bounds__(TPB)
 #endif
         if (i < n) {
             const int slot = queue ? queue[i] : i;
-            shade_slot<MODE>(sc, pp, prm, slot, i, pp.hprim[slot], &s_lobes[threadIdx.x], ctr, sss, shaded, nee_recs SH_STATS_ARG);
+            shade_slot<MODE>(sc, pp, prm, slot, i, &s_lobes[threadIdx.x], ctr, sss, shaded, nee_recs SH_STATS_ARG);
         }
 #ifdef SH_STATS
         SH_T(shs, SH_STORE);
