@@ -276,7 +276,7 @@ static __device__ unsigned long long g_pt_stats[PS_N];
  * through the reference's tree from their start: the same answer as ever, for every ray.  The fast tree's boxes are wider than
  * the primitives' bounds (they hold every hit point a primitive can report), so culling by them loses no candidate. */
 #define FZ_WIDEN 1.00001f
-template <class Source, bool COUNT, bool FAST = false>
+template <class Source, bool COUNT, bool FAST = false, int TOP_STAGED = TOP_LDS_NODES>
 PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *staged, const float4 *top_staged, unsigned *total_nodes,
                          unsigned *total_items) {
     int ovf[OVF_STACK];
@@ -443,7 +443,7 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *s
                      * the upper levels of the tree this kernel's rays walk come from the block's LDS copy */
                     float4 q0, q1, q2, q3, q4, q5;
                     const int tl = tnode - top_root;
-                    if (top_staged && tl < TOP_LDS_NODES) {
+                    if (top_staged && tl < TOP_STAGED) {
                         const float4 *np = top_staged + tl * TOP_LDS_ROW;
                         q0 = np[0]; q1 = np[1]; q2 = np[2]; q3 = np[3]; q4 = np[4]; q5 = np[5];
                     } else {
@@ -919,13 +919,13 @@ PD void persistent_trace_sched(const DScene &sc, Source src, int *lds, const flo
 #ifndef PT_SCHED
 #define PT_SCHED 0 /* r02 on config[1]: phases in sequence 190.5 ms per 32-spp pass, fullest-phase-first 193.2 */
 #endif
-template <class Source, bool COUNT, bool FAST = false>
+template <class Source, bool COUNT, bool FAST = false, int TOP_STAGED = TOP_LDS_NODES>
 PD void persistent_trace_any(const DScene &sc, Source src, int *lds, const float4 *staged, const float4 *top_staged, unsigned *total_nodes,
                              unsigned *total_items) {
 #if PT_SCHED
     static_assert(!FAST || !PT_SCHED, "the fullest-phase-first variant walks the reference's tree only");
     persistent_trace_sched<Source, COUNT>(sc, src, lds, staged, total_nodes, total_items);
 #else
-    persistent_trace<Source, COUNT, FAST>(sc, src, lds, staged, top_staged, total_nodes, total_items);
+    persistent_trace<Source, COUNT, FAST, TOP_STAGED>(sc, src, lds, staged, top_staged, total_nodes, total_items);
 #endif
 }

@@ -504,6 +504,8 @@ struct PtrContext {
     /* pipeline */
     Lane lanes[N_LANES];
     int next_lane = 0, last_film_lane = -1;
+    int lanes_used = N_LANES; /* passes kept in flight (PTR_LANES=1..N_LANES; else chosen per scene at upload) */
+    bool lanes_forced = false;
     int staged_bounces = 6; /* wavefront bounces before k_finish; adapted from the live counts of finished passes */
     bool staged_fixed = false;
     int stage_div = 1024; /* a bounce is staged while more than slots / stage_div paths are alive (PTR_STAGE_DIV) */
@@ -1126,6 +1128,7 @@ int ptr_create(int device, PtrContext **out) {
     if (const char *e = getenv("PTR_SSS_CHAINS")) ctx->sss_rounds = atoi(e) != 0 ? 1 : 0;
     if (const char *e = getenv("PTR_SSS_CAP_DIV")) { int v = atoi(e); if (v >= 1) ctx->sss_cap_div = v; }
     if (const char *e = getenv("PTR_SSS_EXIT")) ctx->sss_exit_records = atoi(e) != 0;
+    if (const char *e = getenv("PTR_LANES")) { int v = atoi(e); if (v >= 1 && v <= N_LANES) { ctx->lanes_used = v; ctx->lanes_forced = true; } }
     if (const char *e = getenv("PTR_SPREAD")) { /* tuning experiments */
         int v = atoi(e);
         if (v > 0) ctx->spread = v;
@@ -1344,6 +1347,11 @@ int ptr_scene_upload_built(PtrContext *ctx, const PtrBuiltScene *built) {
         for (const DPrim &pr : hs.prims) analytic += pr.type != SH_MESH && pr.type != SH_CLOUD ? 1 : 0;
         sc.trace_waves = ctx->trace_waves_forced ? ctx->trace_waves_forced : (analytic >= ctx->wide_from ? PT_WAVES_WIDE : PT_WAVES);
         if (!ctx->persist_blocks_forced) ctx->persist_blocks = ctx->n_cus * sc.trace_waves;
+        /* Passes in flight.  Six overlap the tail of one pass's launches with the bulk of another's; where a launch lasts 15-20 ms
+         * (a top level of a hundred analytic primitives) there is no tail to speak of and the passes only take each other's
+         * cache: configs[2] 671 ms per step with six, 654 with four, 641 with two, 639 with one (configs[0], [1], [5]: six is
+         * best; [3], [4]: three and six within 3 %). */
+        if (!ctx->lanes_forced) ctx->lanes_used = analytic >= 32 ? 2 : N_LANES;
     }
     sc.n_nodes = (int)hs.nodes.size();
     sc.n_items = (int)hs.items.size();
@@ -1547,7 +1555,7 @@ int ptr_render(PtrContext *ctx, int ns, int integrator) {
         int nb = (remaining + ctx->spread - 1) / ctx->spread;
         if (nb > (int)nb_cap) nb = (int)nb_cap;
         if (nb < 1) nb = 1;
-        int li = ctx->next_lane++ % N_LANES;
+        int li = ctx->next_lane++ % ctx->lanes_used;
         rc = run_pass(ctx, ctx->lanes[li], li, first, stride, nb, integrator);
         if (rc) return rc;
         used[li] = true;

@@ -20,17 +20,22 @@
 #define PT_LDS_TOPLEVEL 1
 #endif
 #if PT_LDS_TOPLEVEL
-#define PT_STAGED_TOP(sc, fast)                                                                   \
-    __shared__ float4 s_top[TOP_LDS_NODES * TOP_LDS_ROW];                                         \
+/* How many: 64 (7 KB) in the five-wave build, whose five blocks per CU leave 32 KB each beside the 24 KB stack; 128 (14 KB) in the
+ * four-wave build, which has 40 KB each - all 111 inner nodes of configs[2]'s tree (round 2 had to choose between them and the
+ * fourth wave: 128 nodes meant three blocks per CU). */
+#define PT_TOP_STAGED(waves) ((waves) <= PT_WAVES_WIDE ? 2 * TOP_LDS_NODES : TOP_LDS_NODES)
+#define PT_STAGED_TOP(sc, fast, count)                                                            \
+    __shared__ float4 s_top[(count) * TOP_LDS_ROW];                                               \
     {                                                                                             \
         const int nt_ = (fast) ? sc.n_top_fast : sc.n_top;                                        \
-        const int ns_ = nt_ < TOP_LDS_NODES ? nt_ : TOP_LDS_NODES;                                \
+        const int ns_ = nt_ < (count) ? nt_ : (count);                                            \
         const float4 *src_ = reinterpret_cast<const float4 *>(sc.top + ((fast) ? sc.top_fast : 0)); \
         for (int i_ = threadIdx.x; i_ < ns_ * 6; i_ += TRACE_TPB) s_top[(i_ / 6) * TOP_LDS_ROW + (i_ % 6)] = src_[i_]; \
         __syncthreads();                                                                          \
     }
 #else
-#define PT_STAGED_TOP(sc, fast) const float4 *s_top = nullptr
+#define PT_TOP_STAGED(waves) TOP_LDS_NODES
+#define PT_STAGED_TOP(sc, fast, count) const float4 *s_top = nullptr
 #endif
 /* WAVES: wavefronts per SIMD the kernel is compiled for.  Five (96 registers) where a ray spends its time in the meshes; four
  * (128 registers) for scenes with many analytic primitives, whose tests - SDF marching, double-precision quadratics - spill at 96
@@ -39,11 +44,11 @@ template <bool ANY, bool COUNT, bool FAST, int WAVES>
 __global__ void __launch_bounds__(TRACE_TPB) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) k_ptrace(DScene sc, TraceIO io, unsigned long long *ctrs) {
     __shared__ int s_stack[LDS_STACK * TRACE_TPB];
     PT_STAGED_NODES(sc);
-    PT_STAGED_TOP(sc, FAST);
+    PT_STAGED_TOP(sc, FAST, PT_TOP_STAGED(WAVES));
     unsigned tn = 0, ti = 0;
     OneSource<ANY> src;
     src.io = io;
-    persistent_trace_any<OneSource<ANY>, COUNT, FAST>(sc, src, &s_stack[threadIdx.x], s_staged, s_top, &tn, &ti);
+    persistent_trace_any<OneSource<ANY>, COUNT, FAST, PT_TOP_STAGED(WAVES)>(sc, src, &s_stack[threadIdx.x], s_staged, s_top, &tn, &ti);
     if (!ANY && !FAST && io.is_fallback && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctrs[CX_FAST_DEFERRED], (unsigned long long)(io.n_ptr ? *io.n_ptr : io.n));
     if (COUNT) { /* any-hit launches are counted apart: their rays end at the first hit and cost a fraction of a closest-hit ray */
         ctr_flush(ctrs, ANY ? CX_ANY_NODES : C_NODES, tn);
@@ -58,11 +63,11 @@ template <bool COUNT, bool FAST, int WAVES>
 __global__ void __launch_bounds__(TRACE_TPB) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) k_ptrace_bary(DScene sc, TraceIO io, unsigned long long *ctrs) {
     __shared__ int s_stack[LDS_STACK * TRACE_TPB];
     PT_STAGED_NODES(sc);
-    PT_STAGED_TOP(sc, FAST);
+    PT_STAGED_TOP(sc, FAST, PT_TOP_STAGED(WAVES));
     unsigned tn = 0, ti = 0;
     OneSource<false, true> src;
     src.io = io;
-    persistent_trace_any<OneSource<false, true>, COUNT, FAST>(sc, src, &s_stack[threadIdx.x], s_staged, s_top, &tn, &ti);
+    persistent_trace_any<OneSource<false, true>, COUNT, FAST, PT_TOP_STAGED(WAVES)>(sc, src, &s_stack[threadIdx.x], s_staged, s_top, &tn, &ti);
     if (!FAST && io.is_fallback && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctrs[CX_FAST_DEFERRED], (unsigned long long)(io.n_ptr ? *io.n_ptr : io.n));
     if (COUNT) {
         ctr_flush(ctrs, C_NODES, tn);
@@ -76,7 +81,7 @@ __global__ void __launch_bounds__(TRACE_TPB) __attribute__((amdgpu_waves_per_eu(
 k_ptrace3(DScene sc, TraceIO path, TraceIO shadow, TraceIO mis, unsigned long long *ctrs) {
     __shared__ int s_stack[LDS_STACK * TRACE_TPB];
     PT_STAGED_NODES(sc);
-    PT_STAGED_TOP(sc, false);
+    PT_STAGED_TOP(sc, false, TOP_LDS_NODES);
     unsigned tn = 0, ti = 0;
     ThreeSources src;
     src.path = path;
@@ -93,12 +98,12 @@ template <bool FAST, int WAVES>
 __global__ void __launch_bounds__(TRACE_TPB) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) k_ptrace2any(DScene sc, TraceIO a, TraceIO b) {
     __shared__ int s_stack[LDS_STACK * TRACE_TPB];
     PT_STAGED_NODES(sc);
-    PT_STAGED_TOP(sc, FAST);
+    PT_STAGED_TOP(sc, FAST, PT_TOP_STAGED(WAVES));
     unsigned tn = 0, ti = 0;
     TwoAny src;
     src.a = a;
     src.b = b;
-    persistent_trace_any<TwoAny, false, FAST>(sc, src, &s_stack[threadIdx.x], s_staged, s_top, &tn, &ti);
+    persistent_trace_any<TwoAny, false, FAST, PT_TOP_STAGED(WAVES)>(sc, src, &s_stack[threadIdx.x], s_staged, s_top, &tn, &ti);
 }
 void rt_launch_ptrace2any(unsigned blocks, hipStream_t s, const DScene &sc, const TraceIO &a, const TraceIO &b) {
     const bool w4 = sc.trace_waves == PT_WAVES_WIDE;
@@ -121,7 +126,7 @@ __global__ void __launch_bounds__(TRACE_TPB) __attribute__((amdgpu_waves_per_eu(
 k_pchain(DScene sc, uint32_t *planes, const int *n_ptr, int *cursor, unsigned long long *ctrs) {
     __shared__ int s_stack[LDS_STACK * TRACE_TPB];
     PT_STAGED_NODES(sc);
-    PT_STAGED_TOP(sc, false);
+    PT_STAGED_TOP(sc, false, TOP_LDS_NODES);
     unsigned tn = 0, ti = 0, probes = 0;
     ChainSource src;
     src.planes = planes;
