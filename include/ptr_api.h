@@ -167,6 +167,15 @@ typedef struct {
     int32_t _pad;
 } PtrEnvMap;
 
+/* A distant light: Light::Init_Distant / Distant_Sample_Li (src/core/light.cpp:58-63, src/lights/distant.cpp:1-54) as
+ * Aggregator::InsertDistantLight(L, w) queues it (src/core/primitive.cpp:180-189).  Nothing in the reference's scene API calls
+ * that function; the flat scene carries such lights so that this part of lights/*.cpp is reachable.  w points FROM the
+ * scene TO the light (Sample_Li returns wi = Normalize(w)). */
+typedef struct {
+    float L[3];
+    float w[3];
+} PtrDistantLight;
+
 typedef struct {
     int32_t n_primitives, n_meshes, n_clouds, n_images;
     const PtrPrimitive *primitives; /* insertion order == hPrimitives, scene.cpp:70 */
@@ -177,6 +186,10 @@ typedef struct {
     int32_t has_envmap;
     int32_t _pad;
     PtrEnvMap envmap; /* InsertEXRLightMap scene.cpp:703 */
+    /* distant lights, in the light list behind the emissive primitives and the light map */
+    int32_t n_distant;
+    int32_t _pad2;
+    const PtrDistantLight *distant;
 } PtrFlatScene;
 
 /* Camera fields, src/core/camera.h:49-57 (medium comes from the scene, main.cpp:428) */

@@ -263,6 +263,22 @@ void *orc_scene_create(const PtrFlatScene *fs, int rand_calls_before, int meshfi
         BoundingSphere(sc.top.nodes[0].bound, &l.worldCenter, &l.worldRadius); /* infinite.cpp:52-56 */
         sc.lights.push_back(l);
     }
+    /* Aggregator::InsertDistantLight (primitive.cpp:180-189) -> Init_Distant (light.cpp:58-63), Distant_Prepare (distant.cpp:9-13).
+     * The reference's scene API never calls it; the flat scene lists such lights behind the others (include/ptr_api.h). */
+    for (int i = 0; i < fs->n_distant; i++) {
+        const PtrDistantLight &d = fs->distant[i];
+        Light l;
+        l.type = Distant;
+        l.flags = LF_DeltaDirection;
+        l.LightToWorld = XfIdentity(); /* desc.toWorld = Transform() */
+        l.WorldToLight = XfInverse(l.LightToWorld);
+        l.Lemit = V3(d.L[0], d.L[1], d.L[2]);
+        l.prim = -1;
+        l.twoSided = false;
+        l.wLight = Normalize(xf_vec(l.LightToWorld, V3(d.w[0], d.w[1], d.w[2])));
+        BoundingSphere(sc.top.nodes[0].bound, &l.worldCenter, &l.worldRadius);
+        sc.lights.push_back(l);
+    }
     return os;
 }
 

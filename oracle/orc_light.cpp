@@ -120,6 +120,15 @@ static V3 LightSample_Li(const Scene &sc, const Light &l, const Interaction &ref
         vis->p1 = far;
         return EnvLookup(sc.env, uv);
     }
+    case Distant: { /* distant.cpp:19-28 */
+        *wi = l.wLight;
+        *pdf = 1;
+        vis->p0 = ref;
+        Interaction far;
+        far.p = ref.p + l.wLight * 2 * l.worldRadius;
+        vis->p1 = far;
+        return l.Lemit;
+    }
     default: *pdf = 0; return V3(0);
     }
 }

@@ -325,6 +325,12 @@ inline Xf XfFromFlat(const float *m16, const float *mi16) {
         for (int c = 0; c < 4; c++) { t.m[r][c] = m16[r * 4 + c]; t.mInv[r][c] = mi16[r * 4 + c]; }
     return t;
 }
+inline Xf XfIdentity() { /* Transform(), transform.h */
+    Xf t;
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) t.m[r][c] = t.mInv[r][c] = r == c ? 1.f : 0.f;
+    return t;
+}
 inline Xf XfInverse(const Xf &t) { /* transform.h:63-65 */
     Xf r;
     memcpy(r.m, t.mInv, sizeof(r.m));

@@ -168,6 +168,7 @@ struct Light { /* light.h:55-110 */
     bool twoSided;
     V3 worldCenter;
     Float worldRadius;
+    V3 wLight; /* Distant: Normalize(LightToWorld(w)), light.cpp:58-63 */
 };
 
 struct BSSRDFTable { /* bssrdf.h:29-42 */

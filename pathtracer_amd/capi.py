@@ -66,11 +66,16 @@ class PtrEnvMap(C.Structure):
                 ("marg_int", f32), ("_pad", i32)]
 
 
+class PtrDistantLight(C.Structure):
+    _fields_ = [("L", f32 * 3), ("w", f32 * 3)]
+
+
 class PtrFlatScene(C.Structure):
     _fields_ = [("n_primitives", i32), ("n_meshes", i32), ("n_clouds", i32), ("n_images", i32),
                 ("primitives", C.POINTER(PtrPrimitive)), ("meshes", C.POINTER(PtrMesh)),
                 ("clouds", C.POINTER(PtrCloud)), ("images", C.POINTER(PtrImage)),
-                ("camera_medium", PtrMedium), ("has_envmap", i32), ("_pad", i32), ("envmap", PtrEnvMap)]
+                ("camera_medium", PtrMedium), ("has_envmap", i32), ("_pad", i32), ("envmap", PtrEnvMap),
+                ("n_distant", i32), ("_pad2", i32), ("distant", C.POINTER(PtrDistantLight))]
 
 
 class PtrCamera(C.Structure):

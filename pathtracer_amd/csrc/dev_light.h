@@ -294,9 +294,19 @@ PD f3 light_sample_li(const DScene &sc, const DLight &l, const Ref &ref, const f
         p1->n = f3(0.f);
         return env_lookup(sc, uv);
     }
+    if (l.type == LT_DISTANT) { /* distant.cpp:19-28 */
+        const f3 wl(l.wLight[0], l.wLight[1], l.wLight[2]);
+        *wi = wl;
+        *pdf = 1;
+        p1->p = ref.p + wl * 2 * l.worldRadius;
+        p1->pError = f3(0.f);
+        p1->n = f3(0.f);
+        return f3(l.Lemit[0], l.Lemit[1], l.Lemit[2]);
+    }
     *pdf = 0;
     return f3(0.f);
 }
+PD bool light_is_delta(const DLight &l) { return l.type == LT_DISTANT; } /* IsDeltaLight(flags), light.h:39-41: DeltaDirection */
 PD float light_pdf_li(const DScene &sc, const DLight &l, const Ref &ref, const f3 &w) {
     if (l.type == LT_AREA) return shape_pdf_ref(sc, l.prim, ref, w);
     if (l.type == LT_INFINITE) { /* infinite.cpp:85-91 */
@@ -306,7 +316,7 @@ PD float light_pdf_li(const DScene &sc, const DLight &l, const Ref &ref, const f
         if (is_zero(sinTheta)) return 0;
         return d2_pdf(sc, f2(phi * kInv2Pi, theta * kInvPi)) / (2 * kPi * kPi * sinTheta);
     }
-    return 0;
+    return 0; /* distant.cpp:30-32 */
 }
 
 /* ---- medium.cpp ---- */

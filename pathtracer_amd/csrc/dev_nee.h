@@ -178,7 +178,8 @@ PD int build_nee(const DScene &sc, const Ref &it, const BSDF *bsdf, float phase_
             flags |= NEE_A;
             rec.put3(NEE_W(fA), f);
             rec.put3(NEE_W(LiA), Li);
-            rec.put(NEE_W(wA), power_heuristic(1, lightPdf, 1, scatteringPdf));
+            /* a delta light: Ld += f * Li / lightPdf (primitive.cpp:284-285) - the same sum with a weight of exactly 1 */
+            rec.put(NEE_W(wA), light_is_delta(light) ? 1.f : power_heuristic(1, lightPdf, 1, scatteringPdf));
             rec.put(NEE_W(pdfA), lightPdf);
             f3 o, d;
             int med;
@@ -194,7 +195,7 @@ PD int build_nee(const DScene &sc, const Ref &it, const BSDF *bsdf, float phase_
         }
         SH_T(rec.st, SH_NEE_PUT_A);
     }
-    {
+    if (!light_is_delta(light)) { /* primitive.cpp:294 */
         f3 f;
         bool sampledSpecular = false;
         if (bsdf) {

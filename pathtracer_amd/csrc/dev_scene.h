@@ -89,6 +89,7 @@ struct DLight {
     float Lemit[3];
     float l2w[12], w2l[12];
     float worldRadius;
+    float wLight[3]; /* LT_DISTANT: Normalize(LightToWorld(w)), light.cpp:58-63 */
 };
 struct DImage {
     const float *rgb;

@@ -596,6 +596,17 @@ int ptr_bvh_build_mode_get() {
 }
 void ptr_bvh_build_mode_set(int mode) { g_bvh_mode = mode == PTR_BVH_DEVICE_LBVH ? PTR_BVH_DEVICE_LBVH : PTR_BVH_HOST_SAH; }
 
+/* Bounds3::BoundingSphere (geometry.h) of the world bound: radius = Distance(center, pMax) if the centre is inside, else 0 */
+template <class WorldBox> static float world_radius(const WorldBox &world) {
+    float c[3];
+    bool inside = true;
+    for (int a = 0; a < 3; a++) {
+        c[a] = (world.mn[a] + world.mx[a]) * (1.0f / 2);
+        inside = inside && c[a] >= world.mn[a] && c[a] <= world.mx[a];
+    }
+    const float dx = c[0] - world.mx[0], dy = c[1] - world.mx[1], dz = c[2] - world.mx[2];
+    return inside ? sqrtf(dx * dx + dy * dy + dz * dz) : 0;
+}
 int ptr_flatten(const PtrFlatScene *fs, HostScene *hs, std::string *err) {
     if (!fs || !hs) return fail(err, PTR_ERR_INVALID, "null scene");
     if (fs->n_primitives < 0 || fs->n_meshes < 0 || fs->n_clouds < 0 || fs->n_images < 0)
@@ -1016,16 +1027,28 @@ int ptr_flatten(const PtrFlatScene *fs, HostScene *hs, std::string *err) {
         l.prim = -1;
         copy34(l.l2w, e.light_to_world.m);
         copy34(l.w2l, e.light_to_world.mInv);
-        /* Bounds3::BoundingSphere (geometry.h) of the world bound, infinite.cpp:52-56 */
         if (hs->prims.empty()) return fail(err, PTR_ERR_INVALID, "environment map without any primitive");
-        float c[3];
-        bool inside = true;
-        for (int a = 0; a < 3; a++) {
-            c[a] = (world.mn[a] + world.mx[a]) * (1.0f / 2);
-            inside = inside && c[a] >= world.mn[a] && c[a] <= world.mx[a];
-        }
-        float dx = c[0] - world.mx[0], dy = c[1] - world.mx[1], dz = c[2] - world.mx[2];
-        l.worldRadius = inside ? sqrtf(dx * dx + dy * dy + dz * dz) : 0;
+        l.worldRadius = world_radius(world); /* infinite.cpp:52-56 */
+        hs->lights.push_back(l);
+    }
+    /* distant lights (Aggregator::InsertDistantLight, primitive.cpp:180-189; Init_Distant light.cpp:58-63 with an identity
+     * LightToWorld; Distant_Prepare distant.cpp:9-13) */
+    if (fs->n_distant < 0 || (fs->n_distant > 0 && !fs->distant)) return fail(err, PTR_ERR_INVALID, "bad distant-light array");
+    for (int i = 0; i < fs->n_distant; i++) {
+        if (hs->prims.empty()) return fail(err, PTR_ERR_INVALID, "distant light without any primitive");
+        const PtrDistantLight &d = fs->distant[i];
+        DLight l;
+        memset(&l, 0, sizeof(l));
+        l.type = LT_DISTANT;
+        l.prim = -1;
+        for (int k = 0; k < 3; k++) l.Lemit[k] = d.L[k];
+        const float len = sqrtf(d.w[0] * d.w[0] + d.w[1] * d.w[1] + d.w[2] * d.w[2]); /* Normalize: v / Length() = v * (1 / len) */
+        const float inv = 1.f / len;
+        for (int k = 0; k < 3; k++) l.wLight[k] = d.w[k] * inv;
+        const float ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+        memcpy(l.l2w, ident, sizeof(ident));
+        memcpy(l.w2l, ident, sizeof(ident));
+        l.worldRadius = world_radius(world);
         hs->lights.push_back(l);
     }
     /* what the kernels index without checks must be in range before anything is uploaded */

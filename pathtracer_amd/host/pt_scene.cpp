@@ -173,10 +173,18 @@ static PtrContext *default_ctx() {
     return g_default_ctx;
 }
 
+static std::vector<PtrDistantLight> g_distantLights;
+void InsertDistantLight(const Spectrum &L, const vec3f &w) {
+    PtrDistantLight d;
+    d.L[0] = L.x; d.L[1] = L.y; d.L[2] = L.z;
+    d.w[0] = w.x; d.w[1] = w.y; d.w[2] = w.z;
+    g_distantLights.push_back(d);
+}
 void BeginScene(Aggregator *scene) {
     hPrimitives.clear();
     g_cameraMedium.is_valid = 0;
     g_lightMap.valid = false;
+    g_distantLights.clear();
     if (scene && !scene->ctx) scene->ctx = default_ctx();
 }
 
@@ -578,6 +586,7 @@ struct FlatSceneHolder {
     std::vector<PtrMesh> meshes;
     std::vector<PtrCloud> clouds;
     std::vector<PtrImage> images;
+    std::vector<PtrDistantLight> distant;
     LightMapState lm;
 };
 PtrTransform TransformToFlat(const Transform &t) {
@@ -707,6 +716,9 @@ FlatSceneHolder *FlattenScene() {
         e.func = h->lm.func.data(); e.cdf = h->lm.cdf.data(); e.func_int = h->lm.funcInt.data(); e.marg_cdf = h->lm.margCdf.data();
         e.marg_int = h->lm.margInt;
     }
+    h->distant = g_distantLights;
+    fs.n_distant = (int)h->distant.size();
+    fs.distant = h->distant.empty() ? nullptr : h->distant.data();
     return h;
 }
 const PtrFlatScene *FlatSceneGet(const FlatSceneHolder *h) { return &h->fs; }

@@ -153,6 +153,9 @@ void InsertLightMap(const Spectrum *pixels, int width, int height, const Transfo
 /* where that pipeline runs: 0 = on the host (default), 1 = on the current HIP device (ptr_envmap_build: the same tables,
  * bit for bit).  Environment PTR_ENVMAP_BUILD=device selects 1 at start-up.  No counterpart in the reference. */
 void SetLightMapBuilder(int on_device);
+/* Aggregator::InsertDistantLight(L, w) (primitive.cpp:180-189) as a scene function: the reference defines the light
+ * (lights/distant.cpp) and the aggregator method, but nothing in its scene API reaches them.  w: towards the light. */
+void InsertDistantLight(const Spectrum &L, const vec3f &w);
 
 void InsertPrimitive(SphereDescriptor shape, MaterialDescriptor mat);
 void InsertPrimitive(RectDescriptor shape, MaterialDescriptor mat);

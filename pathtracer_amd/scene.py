@@ -317,6 +317,15 @@ class FlatSceneBuilder:
         self._env = (h, view)
         self._keep.append(_EnvTables(h))
 
+    def distant_light(self, L, w):
+        """Aggregator::InsertDistantLight(L, w) (primitive.cpp:180-189): radiance L from direction w (towards the light)"""
+        d = capi.PtrDistantLight()
+        d.L[:] = [float(v) for v in L]
+        d.w[:] = [float(v) for v in w]
+        if not hasattr(self, "_distant"):
+            self._distant = []
+        self._distant.append(d)
+
     def finish(self):
         fs = capi.PtrFlatScene()
         fs.n_primitives, fs.n_meshes, fs.n_clouds, fs.n_images = len(self.prims), len(self.meshes), len(self.clouds), len(self.images)
@@ -330,6 +339,11 @@ class FlatSceneBuilder:
         if getattr(self, "_env", None) is not None:
             fs.has_envmap = 1
             fs.envmap = self._env[1]
+        dl = getattr(self, "_distant", [])
+        if dl:
+            da = (capi.PtrDistantLight * len(dl))(*dl)
+            fs.n_distant, fs.distant = len(dl), da
+            self._keep.append(da)
         self._keep += [pa, ma, ca, ia]
         return PyScene(fs, self._keep)
 
