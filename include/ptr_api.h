@@ -169,7 +169,7 @@ typedef struct {
 
 /* A distant light: Light::Init_Distant / Distant_Sample_Li (src/core/light.cpp:58-63, src/lights/distant.cpp:1-54) as
  * Aggregator::InsertDistantLight(L, w) queues it (src/core/primitive.cpp:180-189).  Nothing in the reference's scene API calls
- * that function; the flat scene carries such lights so that this part of lights/*.cpp is reachable.  w points FROM the
+ * that function; the flat scene carries such lights so that this part of src/lights is reachable.  w points FROM the
  * scene TO the light (Sample_Li returns wi = Normalize(w)). */
 typedef struct {
     float L[3];

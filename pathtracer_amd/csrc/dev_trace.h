@@ -62,9 +62,14 @@ enum { TM_IDLE = 0, TM_TOP = 1, TM_TOPLEAF = 2, TM_GEOM = 3, TM_DONE = 4 /* CONT
 #ifndef PT_POOL
 #define PT_POOL 64
 #endif
-/* lanes that want a top-level step wait until this many do */
+/* lanes that want a top-level step wait until this many do; the build for scenes with many analytic primitives (rt_trace.hip,
+ * PT_WAVES_WIDE) waits for more: there the top level is most of a ray's work and is worth running full (configs[2]: 649 -> 620 ms
+ * per step with 32 instead of 16; configs[1], where it is a sphere and a mesh: 133 -> 139) */
 #ifndef PT_TOP_BATCH
 #define PT_TOP_BATCH 16
+#endif
+#ifndef PT_TOP_BATCH_WIDE
+#define PT_TOP_BATCH_WIDE 32
 #endif
 /* idle lanes wait until this many can be refilled together */
 #ifndef PT_REFILL
@@ -276,7 +281,7 @@ static __device__ unsigned long long g_pt_stats[PS_N];
  * through the reference's tree from their start: the same answer as ever, for every ray.  The fast tree's boxes are wider than
  * the primitives' bounds (they hold every hit point a primitive can report), so culling by them loses no candidate. */
 #define FZ_WIDEN 1.00001f
-template <class Source, bool COUNT, bool FAST = false, int TOP_STAGED = TOP_LDS_NODES>
+template <class Source, bool COUNT, bool FAST = false, int TOP_STAGED = TOP_LDS_NODES, int TOP_BATCH = PT_TOP_BATCH>
 PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *staged, const float4 *top_staged, unsigned *total_nodes,
                          unsigned *total_items) {
     int ovf[OVF_STACK];
@@ -409,7 +414,7 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *s
          * until PT_TOP_BATCH lanes want the top level (a refill brings PT_REFILL at once) or nobody is in a mesh. */
         const long long c1_ = PS_CLOCK();
         const unsigned long long in_top = __ballot(mode == TM_TOP || mode == TM_TOPLEAF);
-        if (__popcll(in_top) >= PT_TOP_BATCH || __ballot(mode == TM_GEOM) == 0)
+        if (__popcll(in_top) >= TOP_BATCH || __ballot(mode == TM_GEOM) == 0)
         while (mode == TM_TOP || mode == TM_TOPLEAF) {
             PS_WAVE_IT(PS_TOP_IT, PS_TOP_LANES);
             int p = -1;            /* the primitive this iteration tests, if any */
@@ -919,13 +924,13 @@ PD void persistent_trace_sched(const DScene &sc, Source src, int *lds, const flo
 #ifndef PT_SCHED
 #define PT_SCHED 0 /* r02 on config[1]: phases in sequence 190.5 ms per 32-spp pass, fullest-phase-first 193.2 */
 #endif
-template <class Source, bool COUNT, bool FAST = false, int TOP_STAGED = TOP_LDS_NODES>
+template <class Source, bool COUNT, bool FAST = false, int TOP_STAGED = TOP_LDS_NODES, int TOP_BATCH = PT_TOP_BATCH>
 PD void persistent_trace_any(const DScene &sc, Source src, int *lds, const float4 *staged, const float4 *top_staged, unsigned *total_nodes,
                              unsigned *total_items) {
 #if PT_SCHED
     static_assert(!FAST || !PT_SCHED, "the fullest-phase-first variant walks the reference's tree only");
     persistent_trace_sched<Source, COUNT>(sc, src, lds, staged, total_nodes, total_items);
 #else
-    persistent_trace<Source, COUNT, FAST, TOP_STAGED>(sc, src, lds, staged, top_staged, total_nodes, total_items);
+    persistent_trace<Source, COUNT, FAST, TOP_STAGED, TOP_BATCH>(sc, src, lds, staged, top_staged, total_nodes, total_items);
 #endif
 }

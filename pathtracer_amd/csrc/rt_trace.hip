@@ -24,6 +24,7 @@
  * four-wave build, which has 40 KB each - all 111 inner nodes of configs[2]'s tree (round 2 had to choose between them and the
  * fourth wave: 128 nodes meant three blocks per CU). */
 #define PT_TOP_STAGED(waves) ((waves) <= PT_WAVES_WIDE ? 2 * TOP_LDS_NODES : TOP_LDS_NODES)
+#define PT_TOP_BATCH_OF(waves) ((waves) <= PT_WAVES_WIDE ? PT_TOP_BATCH_WIDE : PT_TOP_BATCH)
 #define PT_STAGED_TOP(sc, fast, count)                                                            \
     __shared__ float4 s_top[(count) * TOP_LDS_ROW];                                               \
     {                                                                                             \
@@ -48,7 +49,7 @@ __global__ void __launch_bounds__(TRACE_TPB) __attribute__((amdgpu_waves_per_eu(
     unsigned tn = 0, ti = 0;
     OneSource<ANY> src;
     src.io = io;
-    persistent_trace_any<OneSource<ANY>, COUNT, FAST, PT_TOP_STAGED(WAVES)>(sc, src, &s_stack[threadIdx.x], s_staged, s_top, &tn, &ti);
+    persistent_trace_any<OneSource<ANY>, COUNT, FAST, PT_TOP_STAGED(WAVES), PT_TOP_BATCH_OF(WAVES)>(sc, src, &s_stack[threadIdx.x], s_staged, s_top, &tn, &ti);
     if (!ANY && !FAST && io.is_fallback && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctrs[CX_FAST_DEFERRED], (unsigned long long)(io.n_ptr ? *io.n_ptr : io.n));
     if (COUNT) { /* any-hit launches are counted apart: their rays end at the first hit and cost a fraction of a closest-hit ray */
         ctr_flush(ctrs, ANY ? CX_ANY_NODES : C_NODES, tn);
@@ -67,7 +68,7 @@ __global__ void __launch_bounds__(TRACE_TPB) __attribute__((amdgpu_waves_per_eu(
     unsigned tn = 0, ti = 0;
     OneSource<false, true> src;
     src.io = io;
-    persistent_trace_any<OneSource<false, true>, COUNT, FAST, PT_TOP_STAGED(WAVES)>(sc, src, &s_stack[threadIdx.x], s_staged, s_top, &tn, &ti);
+    persistent_trace_any<OneSource<false, true>, COUNT, FAST, PT_TOP_STAGED(WAVES), PT_TOP_BATCH_OF(WAVES)>(sc, src, &s_stack[threadIdx.x], s_staged, s_top, &tn, &ti);
     if (!FAST && io.is_fallback && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctrs[CX_FAST_DEFERRED], (unsigned long long)(io.n_ptr ? *io.n_ptr : io.n));
     if (COUNT) {
         ctr_flush(ctrs, C_NODES, tn);
@@ -103,7 +104,7 @@ __global__ void __launch_bounds__(TRACE_TPB) __attribute__((amdgpu_waves_per_eu(
     TwoAny src;
     src.a = a;
     src.b = b;
-    persistent_trace_any<TwoAny, false, FAST, PT_TOP_STAGED(WAVES)>(sc, src, &s_stack[threadIdx.x], s_staged, s_top, &tn, &ti);
+    persistent_trace_any<TwoAny, false, FAST, PT_TOP_STAGED(WAVES), PT_TOP_BATCH_OF(WAVES)>(sc, src, &s_stack[threadIdx.x], s_staged, s_top, &tn, &ti);
 }
 void rt_launch_ptrace2any(unsigned blocks, hipStream_t s, const DScene &sc, const TraceIO &a, const TraceIO &b) {
     const bool w4 = sc.trace_waves == PT_WAVES_WIDE;
