@@ -12,7 +12,7 @@ from pathtracer_amd import capi
 import common
 import test_gpu_random_scenes as T
 
-SEEDS = [0, 7, 19, 33, 40, 45, 52, 55, 61, 73]
+SEEDS = [0, 7, 19, 33, 40, 45, 52, 55, 61, 73, 80]
 
 
 @pytest.mark.parametrize("seed", SEEDS)

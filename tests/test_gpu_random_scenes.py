@@ -190,6 +190,11 @@ def random_scene(seed):
     if seed % 5 == 4:  # a second medium volume, overlapping whatever is there: three media in one scene with the fog
         med = pa.medium(rand_color(rng, 0.1, 0.4), rand_color(rng, 0.3, 0.9), float(rng.uniform(-0.5, 0.5)))
         b.sphere(float(rng.uniform(0.5, 1.0)), None, S.translate(*rng.uniform(-1.5, 1.5, 3)), medium=med, no_mat=True)
+    if seed >= 78:  # seeds 78..: one or two distant lights next to the emitters (lights/distant.cpp: delta lights in EstimateDirect)
+        for _ in range(int(rng.integers(1, 3))):
+            w = rng.normal(0, 1, 3)
+            w[1] = abs(w[1]) + 0.3  # from above the floor
+            b.distant_light(rand_color(rng, 0.5, 3.0), w)
     sc = b.finish()
     ang, elev = rng.uniform(0, 2 * np.pi), rng.uniform(0.1, 0.6)
     eye = 7.0 * np.array([np.cos(ang) * np.cos(elev), np.sin(elev), np.sin(ang) * np.cos(elev)])
@@ -197,7 +202,7 @@ def random_scene(seed):
     return sc, cam, eye
 
 
-SEEDS = list(range(78))
+SEEDS = list(range(84))
 
 
 @pytest.fixture(scope="module")
