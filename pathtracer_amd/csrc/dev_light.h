@@ -59,8 +59,34 @@ PD int find_interval_cdf(const float *cdf, int size, float u) {
     for (int j = 0; j < 7; j++) c += (lo + j < hi && cdf[lo + j] <= u) ? 1 : 0;
     return clampi(lo + c - 1, 0, size - 2);
 }
-PD float d1_sample(const float *func, const float *cdf, float funcInt, int size, float u, float *pdf, int *off) {
-    int offset = find_interval_cdf(cdf, size, u);
+/* The same index from a 16-ary search tree over cdf[0 .. size) (round 3; built at upload, ptr_runtime.hip build_cdf_tree): a node
+ * is one 64-byte line of 15 separators, level L has 16^L nodes, the separators of a node that covers [s, s + 16 B) are the
+ * entries s + B, s + 2 B, ..., s + 15 B (+inf beyond the array).  A round reads ONE line where the search above reads seven, and
+ * 1024 entries take three dependent rounds instead of four: light sampling is the longest chain of dependent loads of the shade
+ * kernel.  Entry s of every node visited is <= u (it was a separator that was, or it is cdf[0] = 0), so the
+ * count of entries <= u is s + c + 1 at the last level: the same number the bisection finds. */
+#define CDF_TREE_FAN 16
+PD int find_interval_tree(const float *tree, int levels, int size, float u) {
+    int node = 0, s = 0, first = 0, width = 1; /* node within its level, start of its range, first node of the level, nodes in the level */
+    int B = 1;
+    for (int l = 1; l < levels; l++) B *= CDF_TREE_FAN;
+    int c = 0;
+    for (int l = 0; l < levels; l++) {
+        const float4 *np = reinterpret_cast<const float4 *>(tree + (size_t)(first + node) * CDF_TREE_FAN);
+        const float4 k0 = np[0], k1 = np[1], k2 = np[2], k3 = np[3];
+        c = (k0.x <= u) + (k0.y <= u) + (k0.z <= u) + (k0.w <= u) + (k1.x <= u) + (k1.y <= u) + (k1.z <= u) + (k1.w <= u) + (k2.x <= u) +
+            (k2.y <= u) + (k2.z <= u) + (k2.w <= u) + (k3.x <= u) + (k3.y <= u) + (k3.z <= u);
+        s += c * B;
+        first += width;
+        width *= CDF_TREE_FAN;
+        node = node * CDF_TREE_FAN + c;
+        B /= CDF_TREE_FAN;
+    }
+    return clampi(s, 0, size - 2); /* (count - 1 = s + c' + 1 - 1 with the last level's c already added to s) */
+}
+PD float d1_sample(const float *func, const float *cdf, float funcInt, int size, float u, float *pdf, int *off, const float *tree = nullptr,
+                   int tree_levels = 0) {
+    int offset = tree ? find_interval_tree(tree, tree_levels, size, u) : find_interval_cdf(cdf, size, u);
     if (off) *off = offset;
     float du = u - cdf[offset];
     if ((cdf[offset + 1] - cdf[offset]) > 0) du /= (cdf[offset + 1] - cdf[offset]);
@@ -70,9 +96,9 @@ PD float d1_sample(const float *func, const float *cdf, float funcInt, int size,
 PD f2 d2_sample(const DScene &sc, const f2 &u, float *pdf) {
     float p0, p1;
     int v;
-    float d1 = d1_sample(sc.env_func_int, sc.env_marg_cdf, sc.env_marg_int, sc.env_nv, u.y, &p1, &v);
+    float d1 = d1_sample(sc.env_func_int, sc.env_marg_cdf, sc.env_marg_int, sc.env_nv, u.y, &p1, &v, sc.env_marg_tree, sc.env_tree_v_levels);
     float d0 = d1_sample(sc.env_func + (size_t)v * sc.env_nu, sc.env_cdf + (size_t)v * (sc.env_nu + 1), sc.env_func_int[v], sc.env_nu, u.x, &p0,
-                         nullptr);
+                         nullptr, sc.env_cdf_tree ? sc.env_cdf_tree + (size_t)v * sc.env_tree_u_nodes * CDF_TREE_FAN : nullptr, sc.env_tree_u_levels);
     *pdf = p0 * p1;
     return f2(d0, d1);
 }

@@ -137,6 +137,10 @@ struct DScene {
     const int32_t *order;  /* its leaf handles: primitive indices */
     /* environment map */
     const float *env_texels, *env_func, *env_cdf, *env_func_int, *env_marg_cdf;
+    /* the same CDFs as 16-ary search trees (dev_light.h find_interval_tree; built at upload, null when the map is too large):
+     * env_cdf_tree = one tree of env_tree_u_nodes nodes per row, env_marg_tree = one tree */
+    const float *env_cdf_tree, *env_marg_tree;
+    int32_t env_tree_u_levels, env_tree_u_nodes, env_tree_v_levels, env_tree_pad;
     float env_marg_int;
     int32_t env_w, env_h, env_nu, env_nv;
     int32_t n_prims, n_lights, n_nodes, n_items;

@@ -1272,6 +1272,37 @@ int ptr_scene_upload(PtrContext *ctx, const PtrFlatScene *scene) {
     return rc;
 }
 
+/* A CDF's first `size` entries as the 16-ary search tree of dev_light.h find_interval_tree, appended to `out`; returns its levels.
+ * Nodes level by level, 16 floats each: 15 separators and a pad; +inf where the array has ended. */
+static int cdf_tree_levels(int size) {
+    int levels = 1;
+    long long cover = CDF_TREE_FAN;
+    while (cover < size) { cover *= CDF_TREE_FAN; levels++; }
+    return levels;
+}
+static size_t cdf_tree_nodes(int levels) {
+    size_t n = 0, w = 1;
+    for (int l = 0; l < levels; l++) { n += w; w *= CDF_TREE_FAN; }
+    return n;
+}
+static void build_cdf_tree(const float *cdf, int size, int levels, std::vector<float> &out) {
+    long long B = 1;
+    for (int l = 1; l < levels; l++) B *= CDF_TREE_FAN;
+    size_t width = 1;
+    for (int l = 0; l < levels; l++) {
+        for (size_t node = 0; node < width; node++) {
+            const long long s = (long long)node * B * CDF_TREE_FAN;
+            for (int j = 1; j < CDF_TREE_FAN; j++) {
+                const long long i = s + j * B;
+                out.push_back(i < size ? cdf[i] : INFINITY);
+            }
+            out.push_back(INFINITY);
+        }
+        width *= CDF_TREE_FAN;
+        B /= CDF_TREE_FAN;
+    }
+}
+
 int ptr_scene_upload_built(PtrContext *ctx, const PtrBuiltScene *built) {
     int rc = ctx_use(ctx);
     if (rc) return rc;
@@ -1300,6 +1331,22 @@ int ptr_scene_upload_built(PtrContext *ctx, const PtrBuiltScene *built) {
     UP(env_func_int, hs.env_func_int)
     UP(env_marg_cdf, hs.env_marg_cdf)
 #undef UP
+    /* the light map's CDFs once more as 16-ary search trees (dev_light.h): up to 64 MB of them, else the arrays are searched */
+    if (hs.has_env && hs.env_nu > 1 && hs.env_nv > 1) {
+        const int lu = cdf_tree_levels(hs.env_nu), lv = cdf_tree_levels(hs.env_nv);
+        const size_t nu_nodes = cdf_tree_nodes(lu);
+        if (nu_nodes * CDF_TREE_FAN * sizeof(float) * (size_t)hs.env_nv <= ((size_t)64 << 20)) {
+            std::vector<float> tu, tv;
+            tu.reserve(nu_nodes * CDF_TREE_FAN * (size_t)hs.env_nv);
+            for (int v = 0; v < hs.env_nv; v++) build_cdf_tree(hs.env_cdf.data() + (size_t)v * (hs.env_nu + 1), hs.env_nu, lu, tu);
+            build_cdf_tree(hs.env_marg_cdf.data(), hs.env_nv, lv, tv);
+            if ((rc = upload(ctx, tu.data(), tu.size(), &sc.env_cdf_tree))) return rc;
+            if ((rc = upload(ctx, tv.data(), tv.size(), &sc.env_marg_tree))) return rc;
+            sc.env_tree_u_levels = lu;
+            sc.env_tree_u_nodes = (int)nu_nodes;
+            sc.env_tree_v_levels = lv;
+        }
+    }
     std::vector<DImage> dimg(hs.images.size());
     for (size_t i = 0; i < hs.images.size(); i++) {
         if ((rc = upload(ctx, hs.images[i].rgb.data(), hs.images[i].rgb.size(), &dimg[i].rgb))) return rc;
