@@ -214,26 +214,55 @@ PD float disney_clearcoat_pdf(const Lobe &b, const f3 &wo, const f3 &wi) {
     return Dr * abs_cos_theta(wh) / (4 * dot(wo, wh));
 }
 
+/* ---- MicrofacetReflection / MicrofacetTransmission (reflection.cpp) in ONE body each for Pdf and f ----
+ * A rough dielectric (glass material) carries both lobes and a wavefront's lanes pick between them at random, so the two
+ * `case`s ran one after the other for half the lanes each - normalize, D, G1 / G, Fresnel twice.  Here the two lobes share
+ * those evaluations and differ by selects on their inputs and by their (short) final expressions; every lane still performs
+ * exactly the operations of its own lobe, in the reference's order: the same floats (films bit-identical). */
+PD float micro_pdf(const Lobe &b, const f3 &wo, const f3 &wi, bool refl, const f3 *wh_sampled = nullptr) {
+    if (!wh_sampled && (refl ? !same_hemisphere(wo, wi) : same_hemisphere(wo, wi))) return 0;
+    const float eta = cos_theta(wo) > 0 ? (b.B / b.A) : (b.A / b.B); /* (transmission only) */
+    f3 wh;
+    if (wh_sampled) wh = *wh_sampled;
+    else {
+        const f3 wis = refl ? wi : wi * eta;
+        wh = normalize(wo + wis);
+    }
+    const float mf = mf_pdf(b.ax, b.ay, wo, wh);
+    if (refl) {
+        const float dww = dot(wo, wh);
+        return mf / (4 * dww);
+    }
+    const float sqrtDenom = dot(wo, wh) + eta * dot(wi, wh);
+    const float dwh_dwi = absr((eta * eta * dot(wi, wh)) / (sqrtDenom * sqrtDenom));
+    return mf * dwh_dwi;
+}
+PD f3 micro_f(const Lobe &b, const f3 &wo, const f3 &wi, bool refl) {
+    if (!refl && same_hemisphere(wo, wi)) return f3(0.f);
+    const float cosThetaO = refl ? abs_cos_theta(wo) : cos_theta(wo), cosThetaI = refl ? abs_cos_theta(wi) : cos_theta(wi);
+    if (is_zero(cosThetaI) || is_zero(cosThetaO)) return f3(0.f);
+    const float eta = cos_theta(wo) > 0 ? (b.B / b.A) : (b.A / b.B); /* (transmission only) */
+    const f3 wis = refl ? wi : wi * eta;
+    f3 wh = wo + wis; /* reflection: wi + wo, the same sum */
+    if (refl && is_zero(wh.x) && is_zero(wh.y) && is_zero(wh.z)) return f3(0.f);
+    wh = normalize(wh);
+    if (!refl && wh.z < 0) wh = -wh;
+    const float cosF = refl ? dot(wi, faceforward(wh, f3(0, 0, 1))) : dot(wo, wh);
+    const f3 F = fresnel_eval(b, cosF);
+    const float D = mf_D(b.ax, b.ay, wh), G = mf_G(b.ax, b.ay, wo, wi);
+    if (refl) return b.S * D * G * F / (4 * cosThetaI * cosThetaO);
+    const float sqrtDenom = dot(wo, wh) + eta * dot(wi, wh);
+    const float factor = 1 / eta;
+    return (f3(1.f) - F) * b.T * absr(D * G * eta * eta * absdot(wi, wh) * absdot(wo, wh) * factor * factor / (cosThetaI * cosThetaO * sqrtDenom * sqrtDenom));
+}
+
 PD float lobe_pdf_body(const Lobe &b, const f3 &wo, const f3 &wi) {
     switch (b.impl) {
     case LB_LAMBERT_R: case LB_OREN_NAYAR: case LB_BSSRDF_ADAPTER:
     case LB_DISNEY_DIFFUSE: case LB_DISNEY_FAKESS: case LB_DISNEY_RETRO: case LB_DISNEY_SHEEN: return same_hemisphere(wo, wi) ? abs_cos_theta(wi) * kInvPi : 0;
     case LB_DISNEY_CLEARCOAT: return disney_clearcoat_pdf(b, wo, wi);
     case LB_LAMBERT_T: return !same_hemisphere(wo, wi) ? abs_cos_theta(wi) * kInvPi : 0;
-    case LB_MICRO_T: {
-        if (same_hemisphere(wo, wi)) return 0;
-        float eta = cos_theta(wo) > 0 ? (b.B / b.A) : (b.A / b.B);
-        f3 wh = normalize(wo + wi * eta);
-        float sqrtDenom = dot(wo, wh) + eta * dot(wi, wh);
-        float dwh_dwi = absr((eta * eta * dot(wi, wh)) / (sqrtDenom * sqrtDenom));
-        return mf_pdf(b.ax, b.ay, wo, wh) * dwh_dwi;
-    }
-    case LB_MICRO_R: {
-        if (!same_hemisphere(wo, wi)) return 0;
-        f3 wh = normalize(wo + wi);
-        float dww = dot(wo, wh);
-        return mf_pdf(b.ax, b.ay, wo, wh) / (4 * dww);
-    }
+    case LB_MICRO_T: case LB_MICRO_R: return micro_pdf(b, wo, wi, b.impl == LB_MICRO_R);
     case LB_FRESNEL_BLEND: {
         if (!same_hemisphere(wo, wi)) return 0;
         f3 wh = normalize(wo + wi);
@@ -265,29 +294,7 @@ PD f3 lobe_f_body(const Lobe &b, const f3 &wo, const f3 &wi) {
         else { sinAlpha = sinThetaI; tanBeta = sinThetaO / abs_cos_theta(wo); }
         return b.S * (float)kInvPi * (b.A + b.B * maxCos * sinAlpha * tanBeta);
     }
-    case LB_MICRO_T: {
-        if (same_hemisphere(wo, wi)) return f3(0.f);
-        float cosThetaO = cos_theta(wo), cosThetaI = cos_theta(wi);
-        if (is_zero(cosThetaI) || is_zero(cosThetaO)) return f3(0.f);
-        float eta = cos_theta(wo) > 0 ? (b.B / b.A) : (b.A / b.B);
-        f3 wh = normalize(wo + wi * eta);
-        if (wh.z < 0) wh = -wh;
-        f3 F = fresnel_eval(b, dot(wo, wh));
-        float sqrtDenom = dot(wo, wh) + eta * dot(wi, wh);
-        float factor = 1 / eta;
-        return (f3(1.f) - F) * b.T *
-               absr(mf_D(b.ax, b.ay, wh) * mf_G(b.ax, b.ay, wo, wi) * eta * eta * absdot(wi, wh) * absdot(wo, wh) * factor * factor /
-                    (cosThetaI * cosThetaO * sqrtDenom * sqrtDenom));
-    }
-    case LB_MICRO_R: {
-        float cosThetaO = abs_cos_theta(wo), cosThetaI = abs_cos_theta(wi);
-        f3 wh = wi + wo;
-        if (is_zero(cosThetaI) || is_zero(cosThetaO)) return f3(0.f);
-        if (is_zero(wh.x) && is_zero(wh.y) && is_zero(wh.z)) return f3(0.f);
-        wh = normalize(wh);
-        f3 F = fresnel_eval(b, dot(wi, faceforward(wh, f3(0, 0, 1))));
-        return b.S * mf_D(b.ax, b.ay, wh) * mf_G(b.ax, b.ay, wo, wi) * F / (4 * cosThetaI * cosThetaO);
-    }
+    case LB_MICRO_T: case LB_MICRO_R: return micro_f(b, wo, wi, b.impl == LB_MICRO_R);
     case LB_FRESNEL_BLEND: {
         f3 diffuse = (float)(28.f / (23.f * kPi)) * b.S * (f3(1.f) - b.T) * (1 - pow5(1 - .5f * abs_cos_theta(wi))) *
                      (1 - pow5(1 - .5f * abs_cos_theta(wo)));
@@ -431,24 +438,24 @@ PD f3 lobe_sample_f_body(const Lobe &b, const f3 &wo, f3 *wi, const f2 &u, float
         *pdf = 1 - F;
         return ft / abs_cos_theta(*wi);
     }
-    case LB_MICRO_T: {
+    case LB_MICRO_T: case LB_MICRO_R: {
+        /* one body for both (see micro_f): the half-vector sample, the density and the value are evaluated once for a wavefront
+         * whose lanes picked different lobes of a rough dielectric */
+        const bool refl = b.impl == LB_MICRO_R;
         if (is_zero(wo.z)) return f3(0.f);
-        f3 wh = mf_sample_wh(b.ax, b.ay, wo, u);
+        const f3 wh = mf_sample_wh(b.ax, b.ay, wo, u);
         if (dot(wo, wh) < 0) return f3(0.f);
-        float eta = cos_theta(wo) > 0 ? (b.A / b.B) : (b.B / b.A);
-        if (!refract(wo, wh, eta, wi)) return f3(0.f);
-        *pdf = lobe_pdf(b, wo, *wi);
-        return lobe_f(b, wo, *wi);
-    }
-    case LB_MICRO_R: {
-        if (is_zero(wo.z)) return f3(0.f);
-        f3 wh = mf_sample_wh(b.ax, b.ay, wo, u);
-        if (dot(wo, wh) < 0) return f3(0.f);
-        *wi = reflect(wo, wh);
-        if (!same_hemisphere(wo, *wi)) return f3(0.f);
-        float dd = dot(wo, wh);
-        *pdf = mf_pdf(b.ax, b.ay, wo, wh) / (4 * dd);
-        return lobe_f(b, wo, *wi);
+        if (refl) {
+            *wi = reflect(wo, wh);
+            if (!same_hemisphere(wo, *wi)) return f3(0.f);
+        } else {
+            const float eta = cos_theta(wo) > 0 ? (b.A / b.B) : (b.B / b.A);
+            if (!refract(wo, wh, eta, wi)) return f3(0.f);
+        }
+        /* MicrofacetReflection::Sample_f takes its density from the SAMPLED half vector (reflection.cpp), the transmission lobe
+         * calls Pdf(wo, wi), which rebuilds it from the directions */
+        *pdf = micro_pdf(b, wo, *wi, refl, refl ? &wh : nullptr);
+        return micro_f(b, wo, *wi, refl);
     }
     case LB_FRESNEL_BLEND: {
         f2 uu = u;
