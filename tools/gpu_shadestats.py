@@ -7,9 +7,10 @@ import pathtracer_amd as pa
 
 NAMES = ["load", "medium", "make_si", "scatter", "light_sample", "bsdf_eval", "nee_put_a", "bsdf_sample_mis", "light_pdf", "nee_put_b", "bsdf_sample",
          "tail", "store", "wave_rounds"]
-W, H = 1920, 1080
+import bench
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-sc = pa.BuiltScene("knot", W, H, 660, 0)
+fam, p0, p1, W, H = bench.CONFIGS[int(sys.argv[2]) if len(sys.argv) > 2 else 1][:5]
+sc = pa.BuiltScene(fam, W, H, p0, p1)
 r = pa.Renderer(0); r.upload(sc); r.set_camera(sc.camera); r.film_init(W, H, 1)
 fn = pa.capi.hip().ptr_debug_shade_stats
 fn.argtypes = [C.POINTER(C.c_uint64), C.c_int]
