@@ -135,12 +135,14 @@ __global__ void __launch_bounds__(TPB) k_miss(DScene sc, Pipe pp, PassParams prm
     unsigned total = 0, miss = 0;
     const int n = n_ptr ? *n_ptr : n_host;
     const int lane = __lane_id();
-    const int wave = (blockIdx.x * TPB + threadIdx.x) >> 6, n_waves = (gridDim.x * TPB) >> 6;
+    const int wave = threadIdx.x >> 6;
     const int cap = pp.cap;
-    /* a wavefront takes MISS_CHUNK x 64 consecutive entries and reserves its share of the output
-     * queue with ONE atomic: this kernel is fast enough for a per-group atomic on one address
-     * (half a million of them per bounce) to be what it waits for */
-    for (long long base = (long long)wave * 64 * MISS_CHUNK; base < n; base += (long long)n_waves * 64 * MISS_CHUNK) {
+    __shared__ int s_kept[TPB / 64][2], s_out[2];
+    /* a wavefront takes MISS_CHUNK x 64 consecutive entries, and the block's four wavefronts reserve their share of the output
+     * queue with ONE atomic: this kernel is fast enough for a per-group atomic on one address (half a million of them per
+     * bounce, then 65 K per wavefront round, now 16 K per block round) to be what it waits for */
+    for (long long bbase = (long long)blockIdx.x * TPB * MISS_CHUNK; bbase < n; bbase += (long long)gridDim.x * TPB * MISS_CHUNK) {
+        const long long base = bbase + (long long)wave * 64 * MISS_CHUNK;
         int slots[MISS_CHUNK];
         unsigned long long masks[MISS_CHUNK], heavy_masks[MISS_CHUNK];
         int kept = 0, kept_heavy = 0;
@@ -186,11 +188,18 @@ __global__ void __launch_bounds__(TPB) k_miss(DScene sc, Pipe pp, PassParams prm
             kept += __popcll(masks[c]);
             kept_heavy += __popcll(heavy_masks[c]);
         }
-        int out = 0, out_b = 0;
-        if (lane == 0 && kept) out = atomicAdd(cls ? cls : hit_count, kept);
-        if (lane == 1 && kept_heavy) out_b = atomicAdd(cls + 1, kept_heavy); /* (kept_heavy is 0 without cls) */
-        out = __shfl(out, 0, 64);
-        out_b = __shfl(out_b, 1, 64);
+        if (lane == 0) { s_kept[wave][0] = kept; s_kept[wave][1] = kept_heavy; }
+        __syncthreads();
+        if (threadIdx.x < 2) {
+            int sum = 0;
+            for (int w = 0; w < TPB / 64; w++) sum += s_kept[w][threadIdx.x];
+            int at = 0;
+            if (sum) at = threadIdx.x == 0 ? atomicAdd(cls ? cls : hit_count, sum) : atomicAdd(cls + 1, sum); /* (kept_heavy is 0 without cls) */
+            s_out[threadIdx.x] = at;
+        }
+        __syncthreads();
+        int out = s_out[0], out_b = s_out[1];
+        for (int w = 0; w < wave; w++) { out += s_kept[w][0]; out_b += s_kept[w][1]; }
 #pragma unroll
         for (int c = 0; c < MISS_CHUNK; c++) {
             if ((masks[c] >> lane) & 1ull) q_hit[out + __popcll(masks[c] & ((1ull << lane) - 1ull))] = slots[c];
@@ -198,6 +207,7 @@ __global__ void __launch_bounds__(TPB) k_miss(DScene sc, Pipe pp, PassParams prm
             if ((heavy_masks[c] >> lane) & 1ull) q_hit_b[out_b + __popcll(heavy_masks[c] & ((1ull << lane) - 1ull))] = slots[c];
             out_b += __popcll(heavy_masks[c]);
         }
+        __syncthreads(); /* s_kept / s_out are reused by the next round */
     }
     ctr_flush(ctrs, C_TOTAL, total);
     ctr_flush(ctrs, C_MISS, miss);
@@ -220,12 +230,15 @@ __global__ void __launch_bounds__(TPB) k_hitq_join(const int *cls, const int *q_
 #define ROUTE_CHUNK 8
 __global__ void __launch_bounds__(TPB) k_route(const int *n_ptr, const int *queue, const int *route, int *q_next, int *q_nee, int *q_shadow,
                                                int *q_mis, int *counts, int by_place) {
+    /* one reservation per queue and BLOCK round (2048 entries): the four counters share a cache line, and at one atomic per
+     * wavefront round their serialisation, not the streaming, set this kernel's time (1.5 ms for the 60 M entries of bounce 0) */
+    __shared__ int s_mine[TPB / 64][4], s_at[4];
     const int n = *n_ptr;
-    const int lane = __lane_id();
+    const int lane = __lane_id(), wave = threadIdx.x >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    const int wave = (blockIdx.x * TPB + threadIdx.x) >> 6, n_waves = (gridDim.x * TPB) >> 6;
     int *const qs[4] = {q_next, q_nee, q_shadow, q_mis};
-    for (long long base = (long long)wave * 64 * ROUTE_CHUNK; base < n; base += (long long)n_waves * 64 * ROUTE_CHUNK) {
+    for (long long bbase = (long long)blockIdx.x * TPB * ROUTE_CHUNK; bbase < n; bbase += (long long)gridDim.x * TPB * ROUTE_CHUNK) {
+        const long long base = bbase + (long long)wave * 64 * ROUTE_CHUNK;
         int slots[ROUTE_CHUNK], recs[ROUTE_CHUNK], bits[ROUTE_CHUNK];
 #pragma unroll
         for (int c = 0; c < ROUTE_CHUNK; c++) {
@@ -239,7 +252,7 @@ __global__ void __launch_bounds__(TPB) k_route(const int *n_ptr, const int *queu
                 bits[c] = route[i]; /* (the route words are numbered like the queue's entries) */
             }
         }
-        int mine = 0; /* lane q: entries this group adds to queue q */
+        int mine = 0; /* lane q: entries this wavefront adds to queue q */
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             int kept = 0;
@@ -247,11 +260,18 @@ __global__ void __launch_bounds__(TPB) k_route(const int *n_ptr, const int *queu
             for (int c = 0; c < ROUTE_CHUNK; c++) kept += __popcll(__ballot((bits[c] >> q) & 1));
             if (lane == q) mine = kept;
         }
-        int at = 0;
-        if (lane < 4 && mine) at = atomicAdd(counts + lane, mine);
+        if (lane < 4) s_mine[wave][lane] = mine;
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            int total = 0;
+            for (int w = 0; w < TPB / 64; w++) total += s_mine[w][threadIdx.x];
+            s_at[threadIdx.x] = total ? atomicAdd(counts + threadIdx.x, total) : 0;
+        }
+        __syncthreads();
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            int out = __shfl(at, q, 64);
+            int out = s_at[q];
+            for (int w = 0; w < wave; w++) out += s_mine[w][q];
 #pragma unroll
             for (int c = 0; c < ROUTE_CHUNK; c++) {
                 const unsigned long long m = __ballot((bits[c] >> q) & 1);
@@ -259,6 +279,7 @@ __global__ void __launch_bounds__(TPB) k_route(const int *n_ptr, const int *queu
                 out += __popcll(m);
             }
         }
+        __syncthreads(); /* s_mine / s_at are reused by the next round */
     }
 }
 
