@@ -67,7 +67,8 @@ PD bool slab_minmax(float mnx, float mny, float mnz, float mxx, float mxy, float
     const float ay = (mny - o.y) * inv.y, by = (mxy - o.y) * inv.y;
     const float az = (mnz - o.z) * inv.z, bz = (mxz - o.z) * inv.z;
     const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.f));
-    const float t1 = fminf(fminf(fmaxf(ax, bx) * k, fmaxf(ay, by) * k), fminf(fmaxf(az, bz) * k, tmax));
+    /* min(hx k, hy k, hz k) = min(hx, hy, hz) k to the bit: rounding is monotonic and k > 0 (NaN and inf pass through alike) */
+    const float t1 = fminf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * k, tmax);
     *t_entry = t0;
     return t0 <= t1;
 }
@@ -108,6 +109,25 @@ PD int bvh4_visit(const Node128 *nodes, int node, const f3 &ro, const f3 &inv, f
     const float4 *np = reinterpret_cast<const float4 *>(nodes + node);
     /* child i = np[2 i] (min xyz, max x), np[2 i + 1] (max y, max z, ref, -) */
     const float4 a0 = np[0], b0 = np[1], a1 = np[2], b1 = np[3], a2 = np[4], b2 = np[5], a3 = np[6], b3 = np[7];
+    return bvh4_visit_loaded(a0, b0, a1, b1, a2, b2, a3, b3, ro, inv, tmax, r0, r1, r2, r3, tested);
+}
+/* The visit from the quantised copy of the node (dev_scene.h NodeQ): four 16-byte requests instead of eight, the planes decoded
+ * with one fused multiply-add each (the expression ptr_build.cpp quantise_nodes rounded them against) */
+PD int bvh4_visit_q(const NodeQ *qnodes, int node, const f3 &ro, const f3 &inv, float tmax, int &r0, int &r1, int &r2, int &r3, unsigned *tested) {
+    const float4 *np = reinterpret_cast<const float4 *>(qnodes + node);
+    const float4 A = np[0];
+    const int4 R = reinterpret_cast<const int4 *>(np)[1];
+    const uint4 Q = reinterpret_cast<const uint4 *>(np)[2];
+    const uint2 Q2 = *reinterpret_cast<const uint2 *>(np + 3);
+    const uint32_t e = __float_as_uint(A.w);
+    const float sx = __uint_as_float((e & 0xffu) << 23), sy = __uint_as_float(((e >> 8) & 0xffu) << 23), sz = __uint_as_float(((e >> 16) & 0xffu) << 23);
+#define NQ_PLANE(word, c, s, o) __builtin_fmaf((float)(((word) >> (8 * (c))) & 0xffu), s, o)
+#define NQ_A(c) make_float4(NQ_PLANE(Q.x, c, sx, A.x), NQ_PLANE(Q.y, c, sy, A.y), NQ_PLANE(Q.z, c, sz, A.z), NQ_PLANE(Q.w, c, sx, A.x))
+#define NQ_B(c, ref) make_float4(NQ_PLANE(Q2.x, c, sy, A.y), NQ_PLANE(Q2.y, c, sz, A.z), __int_as_float(ref), 0.f)
+    const float4 a0 = NQ_A(0), b0 = NQ_B(0, R.x), a1 = NQ_A(1), b1 = NQ_B(1, R.y), a2 = NQ_A(2), b2 = NQ_B(2, R.z), a3 = NQ_A(3), b3 = NQ_B(3, R.w);
+#undef NQ_PLANE
+#undef NQ_A
+#undef NQ_B
     return bvh4_visit_loaded(a0, b0, a1, b1, a2, b2, a3, b3, ro, inv, tmax, r0, r1, r2, r3, tested);
 }
 /* The same with nodes[0 .. PT_LDS_TOP) - the upper levels of every geometry tree (BVH_NODE_PREFIX, ptr_build.cpp) - read

@@ -25,6 +25,22 @@ struct Node128 {
         int32_t pad;
     } c[4];
 };
+/* The same node for the one-ray-per-lane walkers of the persistent tracer, 64 B: the children's boxes quantised to 8 bits per
+ * plane inside the union of the four (plane = o + q * 2^(e - 127), one fused multiply-add; the builder rounds minima down and
+ * maxima up against exactly that expression, ptr_build.cpp quantise_nodes).  A lane's fetch of a node is per-lane 16-byte
+ * requests to the L1, which serves about one request per clock and CU: the tracer's counters show it saturated,
+ * so a visit costs what it asks for - four requests here, eight for a Node128.  The decoded boxes contain the exact ones and
+ * the slab test is monotonic in the box, so a ray enters every child it entered before: same candidates, same closest hit. */
+#ifndef PT_QNODES
+#define PT_QNODES 0 /* make VARIANT=q EXTRA=-DPT_QNODES=1: built, exact (films identical), measured equal to Node128 on every config - off */
+#endif
+struct NodeQ {
+    float o[3];      /* min corner of the union of the children's boxes */
+    uint32_t e;      /* biased exponents of the axis scales: ex | ey << 8 | ez << 16 */
+    int32_t ref[4];  /* as Node128::Child::ref */
+    uint32_t q[6];   /* min x, min y, min z, max x, max y, max z: byte c belongs to child c */
+    uint32_t pad[2];
+};
 /* Node of the top-level BVH over primitives: the reference's own tree (primitive.cpp:537-582),
  * kept because a few results depend on its visiting order.  Leaf: left = -1, handles
  * order[first .. first+n). */
@@ -121,6 +137,7 @@ struct DTable { /* BSSRDFTable, bssrdf.h:29-42 (100 x 64) */
 
 struct DScene {
     const Node128 *nodes;
+    const NodeQ *qnodes; /* nodes[], quantised (same numbering) */
     const Item48 *items;
     const DPrim *prims;
     const DMat *mats;

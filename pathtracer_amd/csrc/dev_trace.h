@@ -255,6 +255,12 @@ static __device__ unsigned long long g_pt_stats[PS_N];
 #define PS_CLOCK() 0ll
 #endif
 
+/* a node visit of the geometry level: from the quantised nodes (dev_scene.h NodeQ) unless the build stages upper levels in LDS */
+#if PT_QNODES && PT_LDS_TOP == 0
+#define PT_VISIT(node, r0, r1, r2, r3) bvh4_visit_q(sc.qnodes, node, ro, inv, tmax, r0, r1, r2, r3, COUNT ? &rn : nullptr)
+#else
+#define PT_VISIT(node, r0, r1, r2, r3) bvh4_visit_staged(sc.nodes, staged, node, ro, inv, tmax, r0, r1, r2, r3, COUNT ? &rn : nullptr)
+#endif
 #ifndef PT_PREFETCH
 #define PT_PREFETCH 0
 #endif
@@ -554,7 +560,7 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *s
         while (mode == TM_GEOM && node >= 0) {
             PS_WAVE_IT(PS_IN_IT, PS_IN_LANES);
             int r0, r1, r2, r3;
-            const int nh = bvh4_visit_staged(sc.nodes, staged, node, ro, inv, tmax, r0, r1, r2, r3, COUNT ? &rn : nullptr);
+            const int nh = PT_VISIT(node, r0, r1, r2, r3);
 #if PT_PREFETCH
             pf_acc ^= pf_pending;
             if (nh > 1) { /* touch the line the pop after this subtree will want: the nearest sibling's node or its first leaf item */
@@ -795,7 +801,7 @@ PD void persistent_trace_sched(const DScene &sc, Source src, int *lds, const flo
             if (mode == TS_IN) {
                 PS_WAVE_IT(PS_IN_IT, PS_IN_LANES);
                 int r0, r1, r2, r3;
-                const int nh = bvh4_visit_staged(sc.nodes, staged, node, ro, inv, tmax, r0, r1, r2, r3, COUNT ? &rn : nullptr);
+                const int nh = PT_VISIT(node, r0, r1, r2, r3);
                 if (nh == 0) PT_GEOM_NEXT();
                 else {
                     if (sp + 3 <= LDS_STACK) { /* the usual case: three unconditional LDS stores, farthest child deepest */

@@ -84,6 +84,55 @@ DMedium conv_medium(const PtrMedium &pm) {
 inline float as_float(int32_t v) { float f; memcpy(&f, &v, 4); return f; }
 
 /* ---- binned SAH build ----------------------------------------------------------------- */
+/* NodeQ (dev_scene.h) from Node128: per axis the smallest power-of-two step whose 255th multiple reaches the far side of the
+ * union box, then each child plane rounded outwards AGAINST THE DECODE EXPRESSION ITSELF (fmaf(q, step, origin), what
+ * dev_isect.h bvh4_visit_q computes), so that the decoded box contains the exact one whatever the rounding of that sum. */
+static void quantise_nodes(const std::vector<Node128> &nodes, std::vector<NodeQ> *out) {
+    out->assign(nodes.size(), NodeQ());
+    for (size_t i = 0; i < nodes.size(); i++) {
+        const Node128 &nd = nodes[i];
+        NodeQ &q = (*out)[i];
+        memset(&q, 0, sizeof(q));
+        float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+        bool any = false;
+        for (int c = 0; c < 4; c++) {
+            q.ref[c] = nd.c[c].ref;
+            if (nd.c[c].ref == BVH_NO_CHILD) continue;
+            for (int a = 0; a < 3; a++) {
+                lo[a] = any ? std::min(lo[a], nd.c[c].mn[a]) : nd.c[c].mn[a];
+                hi[a] = any ? std::max(hi[a], nd.c[c].mx[a]) : nd.c[c].mx[a];
+            }
+            any = true;
+        }
+        for (int a = 0; a < 3; a++) {
+            q.o[a] = lo[a];
+            int e = 1; /* step = 2^(e - 127), e in 1 .. 254 */
+            {
+                const float ext = hi[a] - lo[a];
+                if (ext > 0 && std::isfinite(ext)) {
+                    int ex;
+                    std::frexp(ext / 255.f, &ex); /* ext / 255 = m 2^ex, m in [0.5, 1): 2^ex >= ext / 255 */
+                    e = std::min(254, std::max(1, ex + 127));
+                }
+            }
+            auto step_of = [](int e_) { uint32_t u = (uint32_t)e_ << 23; float f; memcpy(&f, &u, 4); return f; };
+            while (e < 254 && !(std::fmaf(255.f, step_of(e), lo[a]) >= hi[a])) e++;
+            const float st = step_of(e);
+            q.e |= (uint32_t)e << (8 * a);
+            for (int c = 0; c < 4; c++) {
+                if (nd.c[c].ref == BVH_NO_CHILD) continue;
+                int ql = (int)std::floor((nd.c[c].mn[a] - lo[a]) / st), qh = (int)std::ceil((nd.c[c].mx[a] - lo[a]) / st);
+                ql = std::min(255, std::max(0, ql));
+                qh = std::min(255, std::max(0, qh));
+                while (ql > 0 && std::fmaf((float)ql, st, lo[a]) > nd.c[c].mn[a]) ql--;
+                while (qh < 255 && std::fmaf((float)qh, st, lo[a]) < nd.c[c].mx[a]) qh++;
+                q.q[a] |= (uint32_t)ql << (8 * c);
+                q.q[3 + a] |= (uint32_t)qh << (8 * c);
+            }
+        }
+    }
+}
+
 /* node of the intermediate binary SAH tree (host only; collapsed into Node128 below) */
 struct Node64 {
     float lmin[3], lmax[3];
@@ -809,6 +858,8 @@ int ptr_flatten(const PtrFlatScene *fs, HostScene *hs, std::string *err) {
         for (int32_t &r : mesh_root) if (r >= 0) r = new_of[r];
         for (int32_t &r : cloud_root) if (r >= 0) r = new_of[r];
     }
+
+    if (PT_QNODES) quantise_nodes(hs->nodes, &hs->qnodes); /* only a build whose tracer reads them */
 
     if (fs->camera_medium.is_valid) {
         hs->view_medium = (int)hs->media.size();

@@ -31,6 +31,7 @@ struct HostTable { /* BSSRDFTable, bssrdf.h:29-42 */
 };
 struct HostScene {
     std::vector<Node128> nodes;
+    std::vector<NodeQ> qnodes; /* nodes[] quantised (ptr_build.cpp quantise_nodes) */
     std::vector<Item48> items;
     std::vector<DPrim> prims;
     std::vector<DMat> mats;

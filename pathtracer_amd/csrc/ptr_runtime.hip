@@ -1336,6 +1336,7 @@ int ptr_scene_upload_built(PtrContext *ctx, const PtrBuiltScene *built) {
 #define UP(field, vec)                                                      \
     if ((rc = upload(ctx, (vec).data(), (vec).size(), &sc.field))) return rc;
     UP(nodes, hs.nodes)
+    UP(qnodes, hs.qnodes)
     UP(items, hs.items)
     UP(prims, hs.prims)
     UP(mats, hs.mats)
@@ -1426,7 +1427,7 @@ int ptr_scene_upload_built(PtrContext *ctx, const PtrBuiltScene *built) {
     sc.view_medium = hs.view_medium;
     sc.has_env = hs.has_env;
     ctx->sc = sc;
-    ctx->bvh_bytes = (int64_t)(hs.nodes.size() * sizeof(Node128) + hs.items.size() * sizeof(Item48));
+    ctx->bvh_bytes = (int64_t)(hs.nodes.size() * sizeof(Node128) + hs.qnodes.size() * sizeof(NodeQ) + hs.items.size() * sizeof(Item48));
     ctx->bvh_build = built_info(hs);
     ctx->scene_has_media = hs.has_media;
     ctx->scene_has_sss = !hs.tables.empty();
