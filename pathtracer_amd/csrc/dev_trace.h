@@ -261,6 +261,13 @@ static __device__ unsigned long long g_pt_stats[PS_N];
 #else
 #define PT_VISIT(node, r0, r1, r2, r3) bvh4_visit_staged(sc.nodes, staged, node, ro, inv, tmax, r0, r1, r2, r3, COUNT ? &rn : nullptr)
 #endif
+/* Postponed leaves (Aila & Laine's speculative traversal): a lane that reaches a leaf keeps it aside and walks on - with the
+ * tMax it has - until it reaches the next one, so that more lanes are in the inner-node loop while it runs and more of them
+ * bring a leaf when it ends.  Leaves are still looked into in the order they were met; a node visited before the postponed
+ * leaf has shrunk tMax is visited with the older, larger tMax: more boxes entered, no candidate lost. */
+#ifndef PT_SPEC
+#define PT_SPEC 0 /* measured (round 3): films identical, closest-hit launch 6.53-6.55 ms against 6.45-6.46 without - off */
+#endif
 #ifndef PT_PREFETCH
 #define PT_PREFETCH 0
 #endif
@@ -308,6 +315,9 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *s
     bool hit = false;
     /* (in TM_TOPLEAF tnode holds the end of the leaf's handle range: a node is only named again by the pop that leaves the leaf) */
     int tnode = -1, leaf_pos = 0, cp = -1, node = 0, sp = 0;
+#if PT_SPEC
+    int pleaf = 0; /* a leaf the lane has met and not yet looked into (0: none): it walks on to its next leaf first, see the geometry level */
+#endif
     unsigned rn = 0, ri = 0; /* per-ray work (COUNT) */
     bool fresh = false; /* top level: tnode was reached by descent from its parent, where its box has just passed with this tMax */
     float tbest = 0; /* FAST closest-hit walk: the smallest accepted t (tmax is then the slightly wider bound everything is tested with) */
@@ -557,8 +567,22 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *s
 
         /* ---- geometry level: inner nodes until a leaf ---- */
         const long long c2_ = PS_CLOCK();
-        while (mode == TM_GEOM && node >= 0) {
+#if PT_SPEC
+#define PT_IN_ACTIVE (mode == TM_GEOM && (node >= 0 || (pleaf == 0 && node != GEOM_BOTTOM)))
+#define PT_NOT_POSTPONED (pleaf == 0)
+#else
+#define PT_IN_ACTIVE (mode == TM_GEOM && node >= 0)
+#define PT_NOT_POSTPONED true
+#endif
+        while (PT_IN_ACTIVE) {
             PS_WAVE_IT(PS_IN_IT, PS_IN_LANES);
+#if PT_SPEC
+            if (node < 0) { /* a leaf, and none kept aside yet: keep it and take the next entry */
+                pleaf = node;
+                node = PT_POP();
+            }
+            if (node >= 0) {
+#endif
             int r0, r1, r2, r3;
             const int nh = PT_VISIT(node, r0, r1, r2, r3);
 #if PT_PREFETCH
@@ -571,7 +595,7 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *s
 #endif
             if (nh == 0) {
                 node = PT_POP();
-                if (node == GEOM_BOTTOM) PT_LEAVE_GEOM();
+                if (node == GEOM_BOTTOM && PT_NOT_POSTPONED) PT_LEAVE_GEOM(); /* (with a leaf kept aside: after the leaf) */
             } else {
                 if (sp + 3 <= LDS_STACK) { /* the usual case: three unconditional LDS stores, farthest child deepest */
                     lds[sp * TRACE_TPB] = nh == 4 ? r3 : (nh == 3 ? r2 : r1);
@@ -585,14 +609,23 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *s
                 }
                 node = r0;
             }
-            if (__popcll(__ballot(mode == TM_GEOM && node >= 0)) < PT_MIN_ACTIVE) break;
+#if PT_SPEC
+            }
+#endif
+            if (__popcll(__ballot(PT_IN_ACTIVE)) < PT_MIN_ACTIVE) break;
         }
 
         /* ---- leaf ---- */
         const long long c3_ = PS_CLOCK();
+#if PT_SPEC
+        if (mode == TM_GEOM && (pleaf != 0 || node < 0)) { /* (in a mesh, node == GEOM_BOTTOM only with a leaf kept aside) */
+            PS_WAVE_IT(PS_LEAF_ENTRY, PS_LEAF_ENTRY_LANES);
+            unsigned packed = (unsigned)(-((pleaf != 0 ? pleaf : node) + 1));
+#else
         if (mode == TM_GEOM && node < 0) {
             PS_WAVE_IT(PS_LEAF_ENTRY, PS_LEAF_ENTRY_LANES);
             unsigned packed = (unsigned)(-(node + 1));
+#endif
             unsigned first = packed & 0x07FFFFFFu, n = (packed >> 27) + 1;
             bool ended = false, deferred = false;
             /* FAST closest hit: the first item accepted after a hit on ANOTHER primitive is a second candidate (inside one
@@ -629,10 +662,18 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *s
 #undef PT_FZ_ACCEPT_ITEM
             if (deferred) PT_DEFER();
             else if (ended) PT_FINISH();
+#if PT_SPEC
+            else if (pleaf != 0) { /* the leaf kept aside is done; `node` is what the lane walked on to: an inner node, the next leaf, or the end */
+                if (node == GEOM_BOTTOM) PT_LEAVE_GEOM();
+            }
+#endif
             else {
                 node = PT_POP();
                 if (node == GEOM_BOTTOM) PT_LEAVE_GEOM();
             }
+#if PT_SPEC
+            pleaf = 0;
+#endif
         }
 #ifdef PT_STATS
         const long long c4_ = clock64();
