@@ -326,7 +326,7 @@ def main():
         verts_per_launch = sx["shaded_vertices"] / sh_launches
         bytes_per_vertex = 192.0 + 192.0 * sx["nee_records"] / max(1, sx["shaded_vertices"])
         sh_achieved = bytes_per_vertex * verts_per_launch / (sh_avg_ms * 1e-3) / 1e9 if sh_avg_ms > 0 else 0.0
-        sh_traffic = measured_traffic(summary, "k_shade<0>", args.config) or measured_traffic(summary, "k_shade<false>", args.config)
+        sh_traffic = measured_traffic(summary, "k_shade<0", args.config) or measured_traffic(summary, "k_shade<false>", args.config)  # (k_shade<0, 3>: mode, integrator)
         cam_rate = prim_all / dt_max if not args.roofline_only else None
         out = {
             "metric": "Mrays/s (incoherent bounces)",
