@@ -400,6 +400,9 @@ PD bool proc_hit_t(const DScene &sc, const DPrim &pr, const f3 &ro, const f3 &rd
 
 /* Shape::Intersect of an analytic primitive: hit distance only (the interaction is rebuilt by
  * make_si for the one hit that survives) */
+/* PROC = false: for scenes without SDF shapes (DScene::has_proc) - their sphere tracing is what a tracer kernel's registers are
+ * sized by (70-80 spilled at 96 with it, none without) */
+template <bool PROC = true>
 PD bool shape_hit_t(const DScene &sc, const DPrim &pr, const f3 &ro, const f3 &rd, float tmax, float *tHit, int *face) {
     *face = 0;
     switch (pr.type) {
@@ -410,7 +413,9 @@ PD bool shape_hit_t(const DScene &sc, const DPrim &pr, const f3 &ro, const f3 &r
     }
     case SH_RECT: return rect_hit_t(pr, ro, rd, tmax, tHit);
     case SH_DISK: return disk_hit_t(pr, ro, rd, tmax, tHit);
-    case SH_SPHERE_PROC: case SH_BOX_PROC: case SH_TOY: return proc_hit_t(sc, pr, ro, rd, tmax, tHit, face);
+    case SH_SPHERE_PROC: case SH_BOX_PROC: case SH_TOY:
+        if (PROC) return proc_hit_t(sc, pr, ro, rd, tmax, tHit, face);
+        return false;
     default: return false;
     }
 }

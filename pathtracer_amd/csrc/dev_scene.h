@@ -166,6 +166,7 @@ struct DScene {
     int32_t top_fast;   /* root of the fast tree over the same primitives (ptr_build.cpp build_fast_top), top[top_fast .. top_fast + n_top_fast); 0: none */
     int32_t n_top_fast;
     int32_t trace_waves; /* which build of the persistent tracer the scene's launches use (rt_trace.hip): PT_WAVES or PT_WAVES_WIDE */
+    int32_t has_proc;    /* some primitive is an SDF shape (SH_SPHERE_PROC / SH_BOX_PROC / SH_TOY): the tracer builds with their code (rt_trace.hip) */
 };
 
 struct DCamera {

@@ -294,7 +294,7 @@ static __device__ unsigned long long g_pt_stats[PS_N];
  * through the reference's tree from their start: the same answer as ever, for every ray.  The fast tree's boxes are wider than
  * the primitives' bounds (they hold every hit point a primitive can report), so culling by them loses no candidate. */
 #define FZ_WIDEN 1.00001f
-template <class Source, bool COUNT, bool FAST = false, int TOP_STAGED = TOP_LDS_NODES, int TOP_BATCH = PT_TOP_BATCH>
+template <class Source, bool COUNT, bool FAST = false, int TOP_STAGED = TOP_LDS_NODES, int TOP_BATCH = PT_TOP_BATCH, bool PROC = true>
 PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *staged, const float4 *top_staged, unsigned *total_nodes,
                          unsigned *total_items) {
     int ovf[OVF_STACK];
@@ -539,7 +539,7 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *s
                     const long long cp0_ = clock64();
                     PS_WAVE_IT(PS_TOPPRIM_IT, PS_TOPPRIM_LANES);
 #endif
-                    const bool ph_ = shape_hit_t(sc, pr, ro, rd, tmax, &t, &face);
+                    const bool ph_ = shape_hit_t<PROC>(sc, pr, ro, rd, tmax, &t, &face);
 #ifdef PT_STATS
                     st_[PS_CYC_TOPPRIM] += clock64() - cp0_;
 #endif
@@ -971,13 +971,13 @@ PD void persistent_trace_sched(const DScene &sc, Source src, int *lds, const flo
 #ifndef PT_SCHED
 #define PT_SCHED 0 /* r02 on config[1]: phases in sequence 190.5 ms per 32-spp pass, fullest-phase-first 193.2 */
 #endif
-template <class Source, bool COUNT, bool FAST = false, int TOP_STAGED = TOP_LDS_NODES, int TOP_BATCH = PT_TOP_BATCH>
+template <class Source, bool COUNT, bool FAST = false, int TOP_STAGED = TOP_LDS_NODES, int TOP_BATCH = PT_TOP_BATCH, bool PROC = true>
 PD void persistent_trace_any(const DScene &sc, Source src, int *lds, const float4 *staged, const float4 *top_staged, unsigned *total_nodes,
                              unsigned *total_items) {
 #if PT_SCHED
     static_assert(!FAST || !PT_SCHED, "the fullest-phase-first variant walks the reference's tree only");
     persistent_trace_sched<Source, COUNT>(sc, src, lds, staged, total_nodes, total_items);
 #else
-    persistent_trace<Source, COUNT, FAST, TOP_STAGED, TOP_BATCH>(sc, src, lds, staged, top_staged, total_nodes, total_items);
+    persistent_trace<Source, COUNT, FAST, TOP_STAGED, TOP_BATCH, PROC>(sc, src, lds, staged, top_staged, total_nodes, total_items);
 #endif
 }

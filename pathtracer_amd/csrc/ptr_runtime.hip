@@ -540,6 +540,7 @@ struct PtrContext {
     bool persist_blocks_forced = false;
     int n_cus = 256;
     int trace_waves_forced = 0; /* PTR_TRACE_WAVES=4|5: the tracer build for every scene */
+    bool trace_lean = true; /* PTR_TRACE_LEAN=0: every scene gets the tracer build with the SDF shapes' code */
     int wide_from = 4;          /* analytic primitives from which a scene gets the 128-register build (PTR_TRACE_WIDE_FROM) */
     int nb_max = 1;
     unsigned long long *ctrs = nullptr;
@@ -1131,6 +1132,7 @@ int ptr_create(int device, PtrContext **out) {
     ctx->n_cus = prop.multiProcessorCount;
     ctx->persist_blocks = prop.multiProcessorCount * PT_WAVES;
     if (const char *e = getenv("PTR_TRACE_WAVES")) { int v = atoi(e); if (v == PT_WAVES || v == PT_WAVES_WIDE) ctx->trace_waves_forced = v; }
+    if (const char *e = getenv("PTR_TRACE_LEAN")) ctx->trace_lean = atoi(e) != 0;
     if (const char *e = getenv("PTR_TRACE_WIDE_FROM")) { int v = atoi(e); if (v >= 0) ctx->wide_from = v; }
     if (const char *e = getenv("PTR_STAGED")) { /* tuning experiments: fixed number of staged bounces */
         int v = atoi(e);
@@ -1416,6 +1418,8 @@ int ptr_scene_upload_built(PtrContext *ctx, const PtrBuiltScene *built) {
         for (const DPrim &pr : hs.prims) analytic += pr.type != SH_MESH && pr.type != SH_CLOUD ? 1 : 0;
         sc.trace_waves = ctx->trace_waves_forced ? ctx->trace_waves_forced : (analytic >= ctx->wide_from ? PT_WAVES_WIDE : PT_WAVES);
         if (!ctx->persist_blocks_forced) ctx->persist_blocks = ctx->n_cus * sc.trace_waves;
+        sc.has_proc = ctx->trace_lean ? 0 : 1;
+        for (const DPrim &pr : hs.prims) sc.has_proc |= pr.type == SH_SPHERE_PROC || pr.type == SH_BOX_PROC || pr.type == SH_TOY ? 1 : 0;
         /* Passes in flight.  Six overlap the tail of one pass's launches with the bulk of another's; where a launch lasts 15-20 ms
          * (a top level of a hundred analytic primitives) there is no tail to speak of and the passes only take each other's
          * cache: configs[2] 671 ms per step with six, 654 with four, 641 with two, 639 with one (configs[0], [1], [5]: six is

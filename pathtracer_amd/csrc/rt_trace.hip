@@ -41,7 +41,9 @@
 /* WAVES: wavefronts per SIMD the kernel is compiled for.  Five (96 registers) where a ray spends its time in the meshes; four
  * (128 registers) for scenes with many analytic primitives, whose tests - SDF marching, double-precision quadratics - spill at 96
  * (DScene::trace_waves, ptr_runtime.hip; configs[2]: 22.5 against 16.4 ms per closest-hit launch, configs[1]: 6.77 against 6.80). */
-template <bool ANY, bool COUNT, bool FAST, int WAVES>
+/* PROC: the scene has SDF shapes (procedural sphere / box, origami toys).  A build without their sphere tracing needs ~100 registers
+ * and spills none at 96; with it the same kernel spills 70-80 (DScene::has_proc; configs[1]: 6.44 -> 6.23 ms per closest-hit launch). */
+template <bool ANY, bool COUNT, bool FAST, int WAVES, bool PROC>
 __global__ void __launch_bounds__(TRACE_TPB) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) k_ptrace(DScene sc, TraceIO io, unsigned long long *ctrs) {
     __shared__ int s_stack[LDS_STACK * TRACE_TPB];
     PT_STAGED_NODES(sc);
@@ -49,7 +51,7 @@ __global__ void __launch_bounds__(TRACE_TPB) __attribute__((amdgpu_waves_per_eu(
     unsigned tn = 0, ti = 0;
     OneSource<ANY> src;
     src.io = io;
-    persistent_trace_any<OneSource<ANY>, COUNT, FAST, PT_TOP_STAGED(WAVES), PT_TOP_BATCH_OF(WAVES)>(sc, src, &s_stack[threadIdx.x], s_staged, s_top, &tn, &ti);
+    persistent_trace_any<OneSource<ANY>, COUNT, FAST, PT_TOP_STAGED(WAVES), PT_TOP_BATCH_OF(WAVES), PROC>(sc, src, &s_stack[threadIdx.x], s_staged, s_top, &tn, &ti);
     if (!ANY && !FAST && io.is_fallback && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctrs[CX_FAST_DEFERRED], (unsigned long long)(io.n_ptr ? *io.n_ptr : io.n));
     if (COUNT) { /* any-hit launches are counted apart: their rays end at the first hit and cost a fraction of a closest-hit ray */
         ctr_flush(ctrs, ANY ? CX_ANY_NODES : C_NODES, tn);
@@ -60,7 +62,7 @@ __global__ void __launch_bounds__(TRACE_TPB) __attribute__((amdgpu_waves_per_eu(
 
 /* closest hit with barycentrics stored (the stand-alone ptr_trace_closest): the two registers they live in are the pipeline's
  * launches' to spare */
-template <bool COUNT, bool FAST, int WAVES>
+template <bool COUNT, bool FAST, int WAVES, bool PROC>
 __global__ void __launch_bounds__(TRACE_TPB) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) k_ptrace_bary(DScene sc, TraceIO io, unsigned long long *ctrs) {
     __shared__ int s_stack[LDS_STACK * TRACE_TPB];
     PT_STAGED_NODES(sc);
@@ -68,7 +70,7 @@ __global__ void __launch_bounds__(TRACE_TPB) __attribute__((amdgpu_waves_per_eu(
     unsigned tn = 0, ti = 0;
     OneSource<false, true> src;
     src.io = io;
-    persistent_trace_any<OneSource<false, true>, COUNT, FAST, PT_TOP_STAGED(WAVES), PT_TOP_BATCH_OF(WAVES)>(sc, src, &s_stack[threadIdx.x], s_staged, s_top, &tn, &ti);
+    persistent_trace_any<OneSource<false, true>, COUNT, FAST, PT_TOP_STAGED(WAVES), PT_TOP_BATCH_OF(WAVES), PROC>(sc, src, &s_stack[threadIdx.x], s_staged, s_top, &tn, &ti);
     if (!FAST && io.is_fallback && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctrs[CX_FAST_DEFERRED], (unsigned long long)(io.n_ptr ? *io.n_ptr : io.n));
     if (COUNT) {
         ctr_flush(ctrs, C_NODES, tn);
@@ -95,7 +97,7 @@ k_ptrace3(DScene sc, TraceIO path, TraceIO shadow, TraceIO mis, unsigned long lo
     }
 }
 
-template <bool FAST, int WAVES>
+template <bool FAST, int WAVES, bool PROC>
 __global__ void __launch_bounds__(TRACE_TPB) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) k_ptrace2any(DScene sc, TraceIO a, TraceIO b) {
     __shared__ int s_stack[LDS_STACK * TRACE_TPB];
     PT_STAGED_NODES(sc);
@@ -104,17 +106,22 @@ __global__ void __launch_bounds__(TRACE_TPB) __attribute__((amdgpu_waves_per_eu(
     TwoAny src;
     src.a = a;
     src.b = b;
-    persistent_trace_any<TwoAny, false, FAST, PT_TOP_STAGED(WAVES), PT_TOP_BATCH_OF(WAVES)>(sc, src, &s_stack[threadIdx.x], s_staged, s_top, &tn, &ti);
+    persistent_trace_any<TwoAny, false, FAST, PT_TOP_STAGED(WAVES), PT_TOP_BATCH_OF(WAVES), PROC>(sc, src, &s_stack[threadIdx.x], s_staged, s_top, &tn, &ti);
 }
+/* the three builds a launch chooses from: four waves per SIMD (scenes with many analytic primitives), five, five without SDF code */
+#define PT_PICK_BUILD(LAUNCH)                                                \
+    do {                                                                     \
+        if (sc.trace_waves == PT_WAVES_WIDE) LAUNCH(PT_WAVES_WIDE, true);    \
+        else if (sc.has_proc) LAUNCH(PT_WAVES, true);                        \
+        else LAUNCH(PT_WAVES, false);                                        \
+    } while (0)
 void rt_launch_ptrace2any(unsigned blocks, hipStream_t s, const DScene &sc, const TraceIO &a, const TraceIO &b) {
-    const bool w4 = sc.trace_waves == PT_WAVES_WIDE;
-    if (sc.top_fast) { /* any hit: every ray may walk the fast tree */
-        if (w4) hipLaunchKernelGGL((k_ptrace2any<true, PT_WAVES_WIDE>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, a, b);
-        else hipLaunchKernelGGL((k_ptrace2any<true, PT_WAVES>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, a, b);
-    } else {
-        if (w4) hipLaunchKernelGGL((k_ptrace2any<false, PT_WAVES_WIDE>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, a, b);
-        else hipLaunchKernelGGL((k_ptrace2any<false, PT_WAVES>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, a, b);
-    }
+#define PT_L2(W, P) hipLaunchKernelGGL((k_ptrace2any<true, W, P>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, a, b)
+#define PT_L2N(W, P) hipLaunchKernelGGL((k_ptrace2any<false, W, P>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, a, b)
+    if (sc.top_fast) PT_PICK_BUILD(PT_L2); /* any hit: every ray may walk the fast tree */
+    else PT_PICK_BUILD(PT_L2N);
+#undef PT_L2
+#undef PT_L2N
 }
 
 /* The BSSRDF probe chains (dev_bssrdf.h): the persistent tracer with a source that continues - every chain is traced segment by
@@ -153,16 +160,17 @@ void rt_launch_ptrace3(bool count, unsigned blocks, hipStream_t s, const DScene 
 bool rt_ptrace_is_fast(bool any, const DScene &sc, const TraceIO &io) { return sc.top_fast != 0 && (any || (io.fb_queue && io.fb_count)); }
 void rt_launch_ptrace(bool any, bool count, unsigned blocks, hipStream_t s, const DScene &sc, const TraceIO &io, unsigned long long *ctrs) {
     const bool fast = rt_ptrace_is_fast(any, sc, io);
-    const bool w4 = sc.trace_waves == PT_WAVES_WIDE;
 #define PT_LAUNCH(A, C, F)                                                                                                     \
     do {                                                                                                                       \
-        if (w4) hipLaunchKernelGGL((k_ptrace<A, C, F, PT_WAVES_WIDE>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, io, ctrs);     \
-        else hipLaunchKernelGGL((k_ptrace<A, C, F, PT_WAVES>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, io, ctrs);             \
+        if (sc.trace_waves == PT_WAVES_WIDE) hipLaunchKernelGGL((k_ptrace<A, C, F, PT_WAVES_WIDE, true>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, io, ctrs); \
+        else if (sc.has_proc) hipLaunchKernelGGL((k_ptrace<A, C, F, PT_WAVES, true>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, io, ctrs); \
+        else hipLaunchKernelGGL((k_ptrace<A, C, F, PT_WAVES, false>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, io, ctrs);      \
     } while (0)
 #define PT_LAUNCH_BARY(C, F)                                                                                                   \
     do {                                                                                                                       \
-        if (w4) hipLaunchKernelGGL((k_ptrace_bary<C, F, PT_WAVES_WIDE>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, io, ctrs);   \
-        else hipLaunchKernelGGL((k_ptrace_bary<C, F, PT_WAVES>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, io, ctrs);           \
+        if (sc.trace_waves == PT_WAVES_WIDE) hipLaunchKernelGGL((k_ptrace_bary<C, F, PT_WAVES_WIDE, true>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, io, ctrs); \
+        else if (sc.has_proc) hipLaunchKernelGGL((k_ptrace_bary<C, F, PT_WAVES, true>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, io, ctrs); \
+        else hipLaunchKernelGGL((k_ptrace_bary<C, F, PT_WAVES, false>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, io, ctrs);    \
     } while (0)
     if (!any && !io.tile_words && (io.b0 || io.b1)) {
         if (fast) { if (count) PT_LAUNCH_BARY(true, true); else PT_LAUNCH_BARY(false, true); }
