@@ -1131,7 +1131,7 @@ int ptr_create(int device, PtrContext **out) {
     /* persistent grid: enough 256-thread blocks to fill every CU at the tracer's occupancy */
     ctx->n_cus = prop.multiProcessorCount;
     ctx->persist_blocks = prop.multiProcessorCount * PT_WAVES;
-    if (const char *e = getenv("PTR_TRACE_WAVES")) { int v = atoi(e); if (v == PT_WAVES || v == PT_WAVES_WIDE) ctx->trace_waves_forced = v; }
+    if (const char *e = getenv("PTR_TRACE_WAVES")) { int v = atoi(e); if (v == PT_WAVES || v == PT_WAVES_WIDE || v == PT_WAVES_LEAN) ctx->trace_waves_forced = v; }
     if (const char *e = getenv("PTR_TRACE_LEAN")) ctx->trace_lean = atoi(e) != 0;
     if (const char *e = getenv("PTR_TRACE_WIDE_FROM")) { int v = atoi(e); if (v >= 0) ctx->wide_from = v; }
     if (const char *e = getenv("PTR_STAGED")) { /* tuning experiments: fixed number of staged bounces */
@@ -1416,10 +1416,19 @@ int ptr_scene_upload_built(PtrContext *ctx, const PtrBuiltScene *built) {
         /* the tracer build: four waves per SIMD (128 registers) once the top level holds many analytic primitives (rt_trace.hip) */
         int analytic = 0;
         for (const DPrim &pr : hs.prims) analytic += pr.type != SH_MESH && pr.type != SH_CLOUD ? 1 : 0;
-        sc.trace_waves = ctx->trace_waves_forced ? ctx->trace_waves_forced : (analytic >= ctx->wide_from ? PT_WAVES_WIDE : PT_WAVES);
+        sc.has_proc = ctx->trace_lean ? 0 : 1; /* (PTR_TRACE_LEAN=0: as if every scene had them) */
+        bool clouds = false;
+        for (const DPrim &pr : hs.prims) {
+            sc.has_proc |= pr.type == SH_SPHERE_PROC || pr.type == SH_BOX_PROC || pr.type == SH_TOY ? 1 : 0;
+            clouds |= pr.type == SH_CLOUD;
+        }
+        /* ... and the builds without the SDF shapes' code where there is no SDF shape and the top level is small: six waves per SIMD,
+         * five where particle clouds bring their double-precision quadratic (configs[3]: 111.6 ms per step with five, 114.6 with six,
+         * 116.7 with the SDF code; configs[1]: 119.5 / 117.0 / 124.0) */
+        sc.trace_waves = ctx->trace_waves_forced ? ctx->trace_waves_forced
+                                                 : (analytic >= ctx->wide_from ? PT_WAVES_WIDE : (!sc.has_proc && !clouds ? PT_WAVES_LEAN : PT_WAVES));
+        if (sc.trace_waves == PT_WAVES_LEAN && sc.has_proc) sc.trace_waves = PT_WAVES; /* (forced: the lean build cannot serve this scene) */
         if (!ctx->persist_blocks_forced) ctx->persist_blocks = ctx->n_cus * sc.trace_waves;
-        sc.has_proc = ctx->trace_lean ? 0 : 1;
-        for (const DPrim &pr : hs.prims) sc.has_proc |= pr.type == SH_SPHERE_PROC || pr.type == SH_BOX_PROC || pr.type == SH_TOY ? 1 : 0;
         /* Passes in flight.  Six overlap the tail of one pass's launches with the bulk of another's; where a launch lasts 15-20 ms
          * (a top level of a hundred analytic primitives) there is no tail to speak of and the passes only take each other's
          * cache: configs[2] 671 ms per step with six, 654 with four, 641 with two, 639 with one (configs[0], [1], [5]: six is

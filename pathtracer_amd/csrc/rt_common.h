@@ -18,6 +18,7 @@ static_assert(TPB == LOBE_STRIDE, "the lobe columns in LDS are strided by the bl
 #define PT_WAVES 5 /* wavefronts per SIMD the persistent tracer is compiled for */
 #endif
 #define PT_WAVES_WIDE 4 /* ... and its second build, with 128 registers, for scenes with many analytic primitives (DScene::trace_waves) */
+#define PT_WAVES_LEAN 6 /* ... and its third, without the SDF shapes' code, for scenes that have none: 80 registers (15-21 spilled), six blocks per CU */
 
 struct Pipe {
     float *ro, *rd;      /* 3 planes of cap floats each */

@@ -23,7 +23,8 @@
 /* How many: 64 (7 KB) in the five-wave build, whose five blocks per CU leave 32 KB each beside the 24 KB stack; 128 (14 KB) in the
  * four-wave build, which has 40 KB each - all 111 inner nodes of configs[2]'s tree (round 2 had to choose between them and the
  * fourth wave: 128 nodes meant three blocks per CU). */
-#define PT_TOP_STAGED(waves) ((waves) <= PT_WAVES_WIDE ? 2 * TOP_LDS_NODES : TOP_LDS_NODES)
+/* The lean build (six waves) serves scenes of a few primitives: 8 nodes (1 KB), so that six blocks of 24 KB stack fit a CU's 160 KB. */
+#define PT_TOP_STAGED(waves) ((waves) >= PT_WAVES_LEAN ? 8 : ((waves) <= PT_WAVES_WIDE ? 2 * TOP_LDS_NODES : TOP_LDS_NODES))
 #define PT_TOP_BATCH_OF(waves) ((waves) <= PT_WAVES_WIDE ? PT_TOP_BATCH_WIDE : PT_TOP_BATCH)
 #define PT_STAGED_TOP(sc, fast, count)                                                            \
     __shared__ float4 s_top[(count) * TOP_LDS_ROW];                                               \
@@ -42,7 +43,8 @@
  * (128 registers) for scenes with many analytic primitives, whose tests - SDF marching, double-precision quadratics - spill at 96
  * (DScene::trace_waves, ptr_runtime.hip; configs[2]: 22.5 against 16.4 ms per closest-hit launch, configs[1]: 6.77 against 6.80). */
 /* PROC: the scene has SDF shapes (procedural sphere / box, origami toys).  A build without their sphere tracing needs ~100 registers
- * and spills none at 96; with it the same kernel spills 70-80 (DScene::has_proc; configs[1]: 6.44 -> 6.23 ms per closest-hit launch). */
+ * and spills none at 96, 15-21 at 80; with it the same kernel spills 70-80 at 96 (DScene::has_proc -> trace_waves = PT_WAVES_LEAN;
+ * configs[1]: 6.44 -> 6.2 ms per closest-hit launch). */
 template <bool ANY, bool COUNT, bool FAST, int WAVES, bool PROC>
 __global__ void __launch_bounds__(TRACE_TPB) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) k_ptrace(DScene sc, TraceIO io, unsigned long long *ctrs) {
     __shared__ int s_stack[LDS_STACK * TRACE_TPB];
@@ -108,12 +110,14 @@ __global__ void __launch_bounds__(TRACE_TPB) __attribute__((amdgpu_waves_per_eu(
     src.b = b;
     persistent_trace_any<TwoAny, false, FAST, PT_TOP_STAGED(WAVES), PT_TOP_BATCH_OF(WAVES), PROC>(sc, src, &s_stack[threadIdx.x], s_staged, s_top, &tn, &ti);
 }
-/* the three builds a launch chooses from: four waves per SIMD (scenes with many analytic primitives), five, five without SDF code */
+/* the builds a launch chooses from: four waves per SIMD (scenes with many analytic primitives), five, and - without the SDF shapes' code - five
+ * (scenes with particle clouds, whose double-precision quadratic wants the registers) and six */
 #define PT_PICK_BUILD(LAUNCH)                                                \
     do {                                                                     \
         if (sc.trace_waves == PT_WAVES_WIDE) LAUNCH(PT_WAVES_WIDE, true);    \
-        else if (sc.has_proc) LAUNCH(PT_WAVES, true);                        \
-        else LAUNCH(PT_WAVES, false);                                        \
+        else if (sc.trace_waves == PT_WAVES_LEAN) LAUNCH(PT_WAVES_LEAN, false); \
+        else if (!sc.has_proc) LAUNCH(PT_WAVES, false);                      \
+        else LAUNCH(PT_WAVES, true);                                         \
     } while (0)
 void rt_launch_ptrace2any(unsigned blocks, hipStream_t s, const DScene &sc, const TraceIO &a, const TraceIO &b) {
 #define PT_L2(W, P) hipLaunchKernelGGL((k_ptrace2any<true, W, P>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, a, b)
@@ -163,14 +167,16 @@ void rt_launch_ptrace(bool any, bool count, unsigned blocks, hipStream_t s, cons
 #define PT_LAUNCH(A, C, F)                                                                                                     \
     do {                                                                                                                       \
         if (sc.trace_waves == PT_WAVES_WIDE) hipLaunchKernelGGL((k_ptrace<A, C, F, PT_WAVES_WIDE, true>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, io, ctrs); \
-        else if (sc.has_proc) hipLaunchKernelGGL((k_ptrace<A, C, F, PT_WAVES, true>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, io, ctrs); \
-        else hipLaunchKernelGGL((k_ptrace<A, C, F, PT_WAVES, false>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, io, ctrs);      \
+        else if (sc.trace_waves == PT_WAVES_LEAN) hipLaunchKernelGGL((k_ptrace<A, C, F, PT_WAVES_LEAN, false>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, io, ctrs); \
+        else if (!sc.has_proc) hipLaunchKernelGGL((k_ptrace<A, C, F, PT_WAVES, false>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, io, ctrs); \
+        else hipLaunchKernelGGL((k_ptrace<A, C, F, PT_WAVES, true>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, io, ctrs);       \
     } while (0)
 #define PT_LAUNCH_BARY(C, F)                                                                                                   \
     do {                                                                                                                       \
         if (sc.trace_waves == PT_WAVES_WIDE) hipLaunchKernelGGL((k_ptrace_bary<C, F, PT_WAVES_WIDE, true>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, io, ctrs); \
-        else if (sc.has_proc) hipLaunchKernelGGL((k_ptrace_bary<C, F, PT_WAVES, true>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, io, ctrs); \
-        else hipLaunchKernelGGL((k_ptrace_bary<C, F, PT_WAVES, false>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, io, ctrs);    \
+        else if (sc.trace_waves == PT_WAVES_LEAN) hipLaunchKernelGGL((k_ptrace_bary<C, F, PT_WAVES_LEAN, false>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, io, ctrs); \
+        else if (!sc.has_proc) hipLaunchKernelGGL((k_ptrace_bary<C, F, PT_WAVES, false>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, io, ctrs); \
+        else hipLaunchKernelGGL((k_ptrace_bary<C, F, PT_WAVES, true>), dim3(blocks), dim3(TRACE_TPB), 0, s, sc, io, ctrs);     \
     } while (0)
     if (!any && !io.tile_words && (io.b0 || io.b1)) {
         if (fast) { if (count) PT_LAUNCH_BARY(true, true); else PT_LAUNCH_BARY(false, true); }
