@@ -224,6 +224,63 @@ PD bool tri_hit_pre(const f3 &ro, const TriRay &tr, float tmax, const f3 &p0, co
     *ob0 = b0; *ob1 = b1; *ob2 = b2;
     return true;
 }
+/* The same test cut in two for the tracer's pair mode (dev_trace.h): everything that does not depend on tMax here - by whichever
+ * lane has been dealt this (ray, triangle) pair - and the two comparisons against tMax * det (mesh.cpp:216-219) in tri_cand_accept,
+ * made by the ray's own lane with the tMax it has when the triangle's turn comes.  The same operations on the same values as
+ * tri_hit_pre.  No candidate: *det = 0 (tri_hit_pre returns false on a zero determinant before it looks at tMax). */
+PD void tri_cand(const f3 &ro, const TriRay &tr, const f3 &p0, const f3 &p1, const f3 &p2, float *tHit, float *otScaled, float *odet, float *ob0,
+                 float *ob1) {
+    *odet = 0.f;
+    f3 p0t = p0 - ro, p1t = p1 - ro, p2t = p2 - ro;
+    p0t = f3(comp(p0t, tr.kx), comp(p0t, tr.ky), comp(p0t, tr.kz));
+    p1t = f3(comp(p1t, tr.kx), comp(p1t, tr.ky), comp(p1t, tr.kz));
+    p2t = f3(comp(p2t, tr.kx), comp(p2t, tr.ky), comp(p2t, tr.kz));
+    const float Sx = tr.Sx, Sy = tr.Sy, Sz = tr.Sz;
+    p0t.x += Sx * p0t.z; p0t.y += Sy * p0t.z;
+    p1t.x += Sx * p1t.z; p1t.y += Sy * p1t.z;
+    p2t.x += Sx * p2t.z; p2t.y += Sy * p2t.z;
+    float e0 = p1t.x * p2t.y - p1t.y * p2t.x;
+    float e1 = p2t.x * p0t.y - p2t.y * p0t.x;
+    float e2 = p0t.x * p1t.y - p0t.y * p1t.x;
+    if (is_zero(e0) || is_zero(e1) || is_zero(e2)) {
+        double p2txp1ty = (double)p2t.x * (double)p1t.y, p2typ1tx = (double)p2t.y * (double)p1t.x;
+        e0 = (float)(p2typ1tx - p2txp1ty);
+        double p0txp2ty = (double)p0t.x * (double)p2t.y, p0typ2tx = (double)p0t.y * (double)p2t.x;
+        e1 = (float)(p0typ2tx - p0txp2ty);
+        double p1txp0ty = (double)p1t.x * (double)p0t.y, p1typ0tx = (double)p1t.y * (double)p0t.x;
+        e2 = (float)(p1typ0tx - p1txp0ty);
+    }
+    if ((e0 < 0 || e1 < 0 || e2 < 0) && (e0 > 0 || e1 > 0 || e2 > 0)) return;
+    float det = e0 + e1 + e2;
+    if (is_zero(det)) return;
+    p0t.z *= Sz; p1t.z *= Sz; p2t.z *= Sz;
+    float tScaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
+    if (det < 0 && tScaled >= 0) return;
+    else if (det > 0 && tScaled <= 0) return;
+    float invDet = 1 / det;
+    float b0 = e0 * invDet, b1 = e1 * invDet;
+    float t = tScaled * invDet;
+    float maxZt = max_comp(abs3(f3(p0t.z, p1t.z, p2t.z)));
+    float deltaZ = gammar(3) * maxZt;
+    float maxXt = max_comp(abs3(f3(p0t.x, p1t.x, p2t.x)));
+    float maxYt = max_comp(abs3(f3(p0t.y, p1t.y, p2t.y)));
+    float deltaX = gammar(5) * (maxXt + maxZt);
+    float deltaY = gammar(5) * (maxYt + maxZt);
+    float deltaE = 2 * (gammar(2) * maxXt * maxYt + deltaY * maxXt + deltaX * maxYt);
+    float maxE = max_comp(abs3(f3(e0, e1, e2)));
+    float deltaT = 3 * (gammar(3) * maxE * maxZt + deltaE * maxZt + deltaZ * maxE) * absr(invDet);
+    if (t <= deltaT) return;
+    *tHit = t;
+    *otScaled = tScaled;
+    *odet = det;
+    *ob0 = b0; *ob1 = b1;
+}
+PD bool tri_cand_accept(float tScaled, float det, float tmax) {
+    if (is_zero(det)) return false;
+    if (det < 0 && tScaled < tmax * det) return false;
+    else if (det > 0 && tScaled > tmax * det) return false;
+    return true;
+}
 PD bool tri_hit(const f3 &ro, const f3 &rd, float tmax, const f3 &p0, const f3 &p1, const f3 &p2, float *tHit, float *ob0,
                 float *ob1, float *ob2) {
     TriRay tr = tri_ray_setup(rd);

@@ -43,6 +43,9 @@ struct TraceIO {
     int is_fallback; /* this IS that second launch (its ray count goes to the CX_FAST_DEFERRED statistic) */
 };
 
+/* persistent_trace<..., PAIRS>: how the leaf phase runs - an item loop per lane (0), or (ray, triangle) pairs dealt to all lanes:
+ * PT_PAIRS_TRI for scenes without particle clouds, PT_PAIRS_MIXED with the item loop kept for the leaves of clouds */
+enum { PT_PAIRS_OFF = 0, PT_PAIRS_TRI = 1, PT_PAIRS_MIXED = 2 };
 #define GEOM_BOTTOM INT32_MIN /* stack entry under a mesh's / cloud's own (= BVH_NO_CHILD, which is never pushed) */
 enum { TM_IDLE = 0, TM_TOP = 1, TM_TOPLEAF = 2, TM_GEOM = 3, TM_DONE = 4 /* CONTINUES sources: the ray has its answer and waits for src.advance */ };
 
@@ -294,9 +297,9 @@ static __device__ unsigned long long g_pt_stats[PS_N];
  * through the reference's tree from their start: the same answer as ever, for every ray.  The fast tree's boxes are wider than
  * the primitives' bounds (they hold every hit point a primitive can report), so culling by them loses no candidate. */
 #define FZ_WIDEN 1.00001f
-template <class Source, bool COUNT, bool FAST = false, int TOP_STAGED = TOP_LDS_NODES, int TOP_BATCH = PT_TOP_BATCH, bool PROC = true>
+template <class Source, bool COUNT, bool FAST = false, int TOP_STAGED = TOP_LDS_NODES, int TOP_BATCH = PT_TOP_BATCH, bool PROC = true, int PAIRS = 0>
 PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *staged, const float4 *top_staged, unsigned *total_nodes,
-                         unsigned *total_items) {
+                         unsigned *total_items, unsigned char *pairs = nullptr) {
     int ovf[OVF_STACK];
 #ifdef PT_STATS
     unsigned long long st_[PS_N] = {};
@@ -319,6 +322,7 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *s
     int pleaf = 0; /* a leaf the lane has met and not yet looked into (0: none): it walks on to its next leaf first, see the geometry level */
 #endif
     unsigned rn = 0, ri = 0; /* per-ray work (COUNT) */
+    bool in_cloud = false; /* PAIRS == PT_PAIRS_MIXED: the primitive the lane is inside is a particle cloud */
     bool fresh = false; /* top level: tnode was reached by descent from its parent, where its box has just passed with this tMax */
     float tbest = 0; /* FAST closest-hit walk: the smallest accepted t (tmax is then the slightly wider bound everything is tested with) */
     const int top_root = FAST ? sc.top_fast : 0;
@@ -528,6 +532,7 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *s
                 }
                 if (geom) {
                     cp = p;
+                    if (PAIRS == PT_PAIRS_MIXED) in_cloud = pr.type == SH_CLOUD;
                     node = pr.root;
                     PT_PUSH(GEOM_BOTTOM); /* under the mesh's entries: popping it leaves the mesh */
                     mode = TM_GEOM;
@@ -617,12 +622,100 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *s
 
         /* ---- leaf ---- */
         const long long c3_ = PS_CLOCK();
+        if constexpr (PAIRS) {
+            /* Pair mode (triangles; PAIRS == PT_PAIRS_MIXED: the leaves of particle clouds take the item loop below).  A leaf holds 1-4 triangles and a
+             * quarter of the wavefront's lanes bring one per round, so the item loop below runs four times for ~15 lanes.  Here the
+             * (ray, triangle) pairs of the round are dealt out to ALL lanes: lane w takes pair w, fetches the ray's constants from
+             * the lane that owns it, and makes the part of the test that does not depend on tMax (tri_cand); then every owner goes
+             * through its leaf's triangles in their order and accepts each against the tMax it has by then (tri_cand_accept) -
+             * the reference's sequence of tests, with the same values.  One round trip to the leaf records instead of up to four. */
+            const bool want = mode == TM_GEOM && node < 0 && !(PAIRS == PT_PAIRS_MIXED && in_cloud);
+            const unsigned long long wm = __ballot(want);
+            if (wm) {
+                const unsigned packed = want ? (unsigned)(-(node + 1)) : 0u;
+                const int nm1 = (int)(packed >> 27); /* triangles in the leaf - 1 */
+                const unsigned long long c1m = __ballot(want && (nm1 & 1)), c2m = __ballot(want && (nm1 & 2));
+                const int pre = __popcll(wm & lt_mask) + __popcll(c1m & lt_mask) + 2 * __popcll(c2m & lt_mask);
+                /* a round serves the owners whose pairs fit its 64 places (lowest lanes first); the others keep their leaf for the next */
+                const bool served = want && pre + nm1 < 64;
+                const unsigned long long sm = __ballot(served);
+                const int total = __popcll(sm) + __popcll(c1m & sm) + 2 * __popcll(c2m & sm);
+                if (served) {
+                    pairs[pre] = (unsigned char)lane;
+                    if (nm1 >= 1) pairs[pre + 1] = (unsigned char)(lane | 64);
+                    if (nm1 >= 2) pairs[pre + 2] = (unsigned char)(lane | 128);
+                    if (nm1 >= 3) pairs[pre + 3] = (unsigned char)(lane | 192);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int dsc = pairs[lane];
+                const int oaddr = (dsc & 63) << 2;
+                /* the owner's ray: origin, shear, and the leaf's first record with the permutation's kz above it */
+                const int w_first = __builtin_amdgcn_ds_bpermute(oaddr, (int)(packed & 0x07FFFFFFu) | (tr.kz << 28));
+                f3 w_ro;
+                TriRay w_tr;
+                w_ro.x = __int_as_float(__builtin_amdgcn_ds_bpermute(oaddr, __float_as_int(ro.x)));
+                w_ro.y = __int_as_float(__builtin_amdgcn_ds_bpermute(oaddr, __float_as_int(ro.y)));
+                w_ro.z = __int_as_float(__builtin_amdgcn_ds_bpermute(oaddr, __float_as_int(ro.z)));
+                w_tr.Sx = __int_as_float(__builtin_amdgcn_ds_bpermute(oaddr, __float_as_int(tr.Sx)));
+                w_tr.Sy = __int_as_float(__builtin_amdgcn_ds_bpermute(oaddr, __float_as_int(tr.Sy)));
+                w_tr.Sz = __int_as_float(__builtin_amdgcn_ds_bpermute(oaddr, __float_as_int(tr.Sz)));
+                float c_t = 0.f, c_ts = 0.f, c_det = 0.f, c_b0 = 0.f, c_b1 = 0.f;
+                int c_face = -1;
+                if (lane < total) {
+                    PS_WAVE_IT(PS_LEAF_IT, PS_LEAF_LANES);
+                    w_tr.kz = (int)((unsigned)w_first >> 28);
+                    w_tr.kx = w_tr.kz + 1; if (w_tr.kx == 3) w_tr.kx = 0;
+                    w_tr.ky = w_tr.kx + 1; if (w_tr.ky == 3) w_tr.ky = 0;
+                    const float4 *ip = reinterpret_cast<const float4 *>(sc.items + (w_first & 0x07FFFFFF) + (dsc >> 6));
+                    const float4 q0 = ip[0], q1 = ip[1], q2 = ip[2];
+                    tri_cand(w_ro, w_tr, f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), &c_t, &c_ts, &c_det, &c_b0, &c_b1);
+                    c_face = __float_as_int(q1.w);
+                }
+                bool ended = false, deferred = false;
+                for (int i = 0; i < 4; i++) {
+                    if (i > 0 && __ballot(served && nm1 >= i) == 0) break; /* (wave-uniform) */
+                    const int saddr = ((pre + i) & 63) << 2;
+                    const float t = __int_as_float(__builtin_amdgcn_ds_bpermute(saddr, __float_as_int(c_t)));
+                    const float ts = __int_as_float(__builtin_amdgcn_ds_bpermute(saddr, __float_as_int(c_ts)));
+                    const float det = __int_as_float(__builtin_amdgcn_ds_bpermute(saddr, __float_as_int(c_det)));
+                    const int face = __builtin_amdgcn_ds_bpermute(saddr, c_face);
+                    float b0 = 0, b1 = 0;
+                    if (Source::BARY) {
+                        b0 = __int_as_float(__builtin_amdgcn_ds_bpermute(saddr, __float_as_int(c_b0)));
+                        b1 = __int_as_float(__builtin_amdgcn_ds_bpermute(saddr, __float_as_int(c_b1)));
+                    }
+                    if (served && nm1 >= i && !ended && !deferred) {
+                        if (COUNT) ri += 1;
+                        if (tri_cand_accept(ts, det, tmax)) {
+                            /* FAST closest hit: the first item accepted after a hit on ANOTHER primitive is a second candidate */
+                            if (PT_FZ_CLOSEST && hit && hp != cp && (t > tbest || tbest < t * FZ_WIDEN)) deferred = true;
+                            else {
+                                if (PT_FZ_CLOSEST) tbest = t;
+                                tmax = t; hp = cp; hf = face; if (Source::BARY) { hb0 = b0; hb1 = b1; } hit = true;
+                                if (PT_ANY) ended = true;
+                            }
+                        }
+                    }
+                }
+                if (served) {
+                    PS_WAVE_IT(PS_LEAF_ENTRY, PS_LEAF_ENTRY_LANES);
+                    if (deferred) PT_DEFER();
+                    else if (ended) PT_FINISH();
+                    else {
+                        node = PT_POP();
+                        if (node == GEOM_BOTTOM) PT_LEAVE_GEOM();
+                    }
+                }
+            }
+        }
 #if PT_SPEC
         if (mode == TM_GEOM && (pleaf != 0 || node < 0)) { /* (in a mesh, node == GEOM_BOTTOM only with a leaf kept aside) */
             PS_WAVE_IT(PS_LEAF_ENTRY, PS_LEAF_ENTRY_LANES);
             unsigned packed = (unsigned)(-((pleaf != 0 ? pleaf : node) + 1));
 #else
-        if (mode == TM_GEOM && node < 0) {
+        if (PAIRS != PT_PAIRS_TRI && mode == TM_GEOM && node < 0 && (PAIRS == 0 || in_cloud)) {
             PS_WAVE_IT(PS_LEAF_ENTRY, PS_LEAF_ENTRY_LANES);
             unsigned packed = (unsigned)(-(node + 1));
 #endif
@@ -971,13 +1064,13 @@ PD void persistent_trace_sched(const DScene &sc, Source src, int *lds, const flo
 #ifndef PT_SCHED
 #define PT_SCHED 0 /* r02 on config[1]: phases in sequence 190.5 ms per 32-spp pass, fullest-phase-first 193.2 */
 #endif
-template <class Source, bool COUNT, bool FAST = false, int TOP_STAGED = TOP_LDS_NODES, int TOP_BATCH = PT_TOP_BATCH, bool PROC = true>
+template <class Source, bool COUNT, bool FAST = false, int TOP_STAGED = TOP_LDS_NODES, int TOP_BATCH = PT_TOP_BATCH, bool PROC = true, int PAIRS = 0>
 PD void persistent_trace_any(const DScene &sc, Source src, int *lds, const float4 *staged, const float4 *top_staged, unsigned *total_nodes,
-                             unsigned *total_items) {
+                             unsigned *total_items, unsigned char *pairs = nullptr) {
 #if PT_SCHED
     static_assert(!FAST || !PT_SCHED, "the fullest-phase-first variant walks the reference's tree only");
     persistent_trace_sched<Source, COUNT>(sc, src, lds, staged, total_nodes, total_items);
 #else
-    persistent_trace<Source, COUNT, FAST, TOP_STAGED, TOP_BATCH, PROC>(sc, src, lds, staged, top_staged, total_nodes, total_items);
+    persistent_trace<Source, COUNT, FAST, TOP_STAGED, TOP_BATCH, PROC, PAIRS>(sc, src, lds, staged, top_staged, total_nodes, total_items, pairs);
 #endif
 }

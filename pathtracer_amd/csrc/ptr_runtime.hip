@@ -1427,7 +1427,7 @@ int ptr_scene_upload_built(PtrContext *ctx, const PtrBuiltScene *built) {
          * 116.7 with the SDF code; configs[1]: 119.5 / 117.0 / 124.0) */
         sc.trace_waves = ctx->trace_waves_forced ? ctx->trace_waves_forced
                                                  : (analytic >= ctx->wide_from ? PT_WAVES_WIDE : (!sc.has_proc && !clouds ? PT_WAVES_LEAN : PT_WAVES));
-        if (sc.trace_waves == PT_WAVES_LEAN && sc.has_proc) sc.trace_waves = PT_WAVES; /* (forced: the lean build cannot serve this scene) */
+        if (sc.trace_waves == PT_WAVES_LEAN && (sc.has_proc || clouds)) sc.trace_waves = PT_WAVES; /* (forced: the lean build has neither the SDF shapes' code nor, in pair mode, the particles') */
         if (!ctx->persist_blocks_forced) ctx->persist_blocks = ctx->n_cus * sc.trace_waves;
         /* Passes in flight.  Six overlap the tail of one pass's launches with the bulk of another's; where a launch lasts 15-20 ms
          * (a top level of a hundred analytic primitives) there is no tail to speak of and the passes only take each other's

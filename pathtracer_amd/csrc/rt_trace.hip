@@ -45,15 +45,26 @@
 /* PROC: the scene has SDF shapes (procedural sphere / box, origami toys).  A build without their sphere tracing needs ~100 registers
  * and spills none at 96, 15-21 at 80; with it the same kernel spills 70-80 at 96 (DScene::has_proc -> trace_waves = PT_WAVES_LEAN;
  * configs[1]: 6.44 -> 6.2 ms per closest-hit launch). */
+/* Pair mode (dev_trace.h): the leaf phase deals (ray, triangle) pairs to all lanes; 64 bytes of LDS per wavefront for the round's pair
+ * list.  The lean build serves scenes of triangle meshes and analytic primitives only (ptr_runtime.hip picks it for scenes without SDF
+ * shapes and without particle clouds); the others keep the item loop for the leaves of clouds.  PT_PAIRS: 0 none, 1 the lean build, 2 all. */
+#ifndef PT_PAIRS
+#define PT_PAIRS 2
+#endif
+#define PT_PAIRS_OF(waves) ((waves) >= PT_WAVES_LEAN ? (PT_PAIRS >= 1 ? PT_PAIRS_TRI : PT_PAIRS_OFF) : (PT_PAIRS >= 2 ? PT_PAIRS_MIXED : PT_PAIRS_OFF))
+#define PT_PAIR_LIST(waves)                                        \
+    __shared__ unsigned char s_pairs[PT_PAIRS_OF(waves) ? TRACE_TPB : 1]; \
+    unsigned char *const pair_list = PT_PAIRS_OF(waves) ? &s_pairs[threadIdx.x & ~63u] : nullptr
 template <bool ANY, bool COUNT, bool FAST, int WAVES, bool PROC>
 __global__ void __launch_bounds__(TRACE_TPB) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) k_ptrace(DScene sc, TraceIO io, unsigned long long *ctrs) {
     __shared__ int s_stack[LDS_STACK * TRACE_TPB];
     PT_STAGED_NODES(sc);
     PT_STAGED_TOP(sc, FAST, PT_TOP_STAGED(WAVES));
+    PT_PAIR_LIST(WAVES);
     unsigned tn = 0, ti = 0;
     OneSource<ANY> src;
     src.io = io;
-    persistent_trace_any<OneSource<ANY>, COUNT, FAST, PT_TOP_STAGED(WAVES), PT_TOP_BATCH_OF(WAVES), PROC>(sc, src, &s_stack[threadIdx.x], s_staged, s_top, &tn, &ti);
+    persistent_trace_any<OneSource<ANY>, COUNT, FAST, PT_TOP_STAGED(WAVES), PT_TOP_BATCH_OF(WAVES), PROC, PT_PAIRS_OF(WAVES)>(sc, src, &s_stack[threadIdx.x], s_staged, s_top, &tn, &ti, pair_list);
     if (!ANY && !FAST && io.is_fallback && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctrs[CX_FAST_DEFERRED], (unsigned long long)(io.n_ptr ? *io.n_ptr : io.n));
     if (COUNT) { /* any-hit launches are counted apart: their rays end at the first hit and cost a fraction of a closest-hit ray */
         ctr_flush(ctrs, ANY ? CX_ANY_NODES : C_NODES, tn);
@@ -69,10 +80,11 @@ __global__ void __launch_bounds__(TRACE_TPB) __attribute__((amdgpu_waves_per_eu(
     __shared__ int s_stack[LDS_STACK * TRACE_TPB];
     PT_STAGED_NODES(sc);
     PT_STAGED_TOP(sc, FAST, PT_TOP_STAGED(WAVES));
+    PT_PAIR_LIST(WAVES);
     unsigned tn = 0, ti = 0;
     OneSource<false, true> src;
     src.io = io;
-    persistent_trace_any<OneSource<false, true>, COUNT, FAST, PT_TOP_STAGED(WAVES), PT_TOP_BATCH_OF(WAVES), PROC>(sc, src, &s_stack[threadIdx.x], s_staged, s_top, &tn, &ti);
+    persistent_trace_any<OneSource<false, true>, COUNT, FAST, PT_TOP_STAGED(WAVES), PT_TOP_BATCH_OF(WAVES), PROC, PT_PAIRS_OF(WAVES)>(sc, src, &s_stack[threadIdx.x], s_staged, s_top, &tn, &ti, pair_list);
     if (!FAST && io.is_fallback && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctrs[CX_FAST_DEFERRED], (unsigned long long)(io.n_ptr ? *io.n_ptr : io.n));
     if (COUNT) {
         ctr_flush(ctrs, C_NODES, tn);
@@ -104,11 +116,12 @@ __global__ void __launch_bounds__(TRACE_TPB) __attribute__((amdgpu_waves_per_eu(
     __shared__ int s_stack[LDS_STACK * TRACE_TPB];
     PT_STAGED_NODES(sc);
     PT_STAGED_TOP(sc, FAST, PT_TOP_STAGED(WAVES));
+    PT_PAIR_LIST(WAVES);
     unsigned tn = 0, ti = 0;
     TwoAny src;
     src.a = a;
     src.b = b;
-    persistent_trace_any<TwoAny, false, FAST, PT_TOP_STAGED(WAVES), PT_TOP_BATCH_OF(WAVES), PROC>(sc, src, &s_stack[threadIdx.x], s_staged, s_top, &tn, &ti);
+    persistent_trace_any<TwoAny, false, FAST, PT_TOP_STAGED(WAVES), PT_TOP_BATCH_OF(WAVES), PROC, PT_PAIRS_OF(WAVES)>(sc, src, &s_stack[threadIdx.x], s_staged, s_top, &tn, &ti, pair_list);
 }
 /* the builds a launch chooses from: four waves per SIMD (scenes with many analytic primitives), five, and - without the SDF shapes' code - five
  * (scenes with particle clouds, whose double-precision quadratic wants the registers) and six */
@@ -139,13 +152,14 @@ k_pchain(DScene sc, uint32_t *planes, const int *n_ptr, int *cursor, unsigned lo
     __shared__ int s_stack[LDS_STACK * TRACE_TPB];
     PT_STAGED_NODES(sc);
     PT_STAGED_TOP(sc, false, TOP_LDS_NODES);
+    PT_PAIR_LIST(PCHAIN_WAVES);
     unsigned tn = 0, ti = 0, probes = 0;
     ChainSource src;
     src.planes = planes;
     src.n_ptr = n_ptr;
     src.counter = cursor;
     src.probes = &probes;
-    persistent_trace<ChainSource, false>(sc, src, &s_stack[threadIdx.x], s_staged, s_top, &tn, &ti);
+    persistent_trace<ChainSource, false, false, TOP_LDS_NODES, PT_TOP_BATCH, true, PT_PAIRS_OF(PCHAIN_WAVES)>(sc, src, &s_stack[threadIdx.x], s_staged, s_top, &tn, &ti, pair_list);
     ctr_flush(ctrs, C_PROBE, probes);
 }
 void rt_launch_pchain(unsigned blocks, hipStream_t s, const DScene &sc, uint32_t *planes, const int *n_ptr, int *cursor, unsigned long long *ctrs) {
