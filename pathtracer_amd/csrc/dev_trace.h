@@ -59,11 +59,11 @@ enum { TM_IDLE = 0, TM_TOP = 1, TM_TOPLEAF = 2, TM_GEOM = 3, TM_DONE = 4 /* CONT
 
 /* inner loops hand control back (to let finished lanes refill) once this few lanes remain in them */
 #ifndef PT_MIN_ACTIVE
-#define PT_MIN_ACTIVE 8
+#define PT_MIN_ACTIVE 16 /* (8 before the leaf phase ran in pair mode: a leaf round is now cheap, leaving the node loop early costs less) */
 #endif
 /* rays a wavefront reserves per atomic on the queue cursor */
 #ifndef PT_POOL
-#define PT_POOL 64
+#define PT_POOL 128 /* every wavefront of every launch adds to ONE cursor, and atomics on one address are served one at a time (~10 ns): at 64 rays per atomic the 361 K atomics of a 23 M-ray launch were 3.6 of its 5.5 ms.  configs[1] closest-hit launches per pass: 32 -> 55 ms, 64 -> 32.9, 128 -> 24.5, 256 -> 24.8, 512 -> 26.6, 1024 -> 30.5 (the rays a wavefront holds back at the end of a launch) */
 #endif
 /* lanes that want a top-level step wait until this many do; the build for scenes with many analytic primitives (rt_trace.hip,
  * PT_WAVES_WIDE) waits for more: there the top level is most of a ray's work and is worth running full (configs[2]: 649 -> 620 ms
@@ -73,6 +73,21 @@ enum { TM_IDLE = 0, TM_TOP = 1, TM_TOPLEAF = 2, TM_GEOM = 3, TM_DONE = 4 /* CONT
 #endif
 #ifndef PT_TOP_BATCH_WIDE
 #define PT_TOP_BATCH_WIDE 32
+#endif
+/* pair mode: the leaf phase runs another round at once while this many pairs wait (0: one round per outer iteration) */
+#ifndef PT_LEAF_REPEAT
+#define PT_LEAF_REPEAT 16 /* configs[1], one pass alone: 125.3 ms with 0, 120.7 with 16 or 32, 121.0 with 48, 121.8 with 1 */
+#endif
+/* the part of a launch's queue that is dealt out to the wavefronts without atomics (persistent_trace) */
+#ifndef PT_STATIC_NUM
+#define PT_STATIC_NUM 0 /* measured, configs[1], closest-hit launches per pass: 0 -> 25.5 ms, 1/2 -> 25.4, 3/4 -> 26.6, 7/8 -> 27.8 (pool 128); 3/4 -> 27.3, 15/16 -> 28.7 (pool 64): what the wavefronts' shares cost differs by more than the rest evens out */
+#endif
+#ifndef PT_STATIC_DEN
+#define PT_STATIC_DEN 4
+#endif
+/* a wavefront reserves its next pool of rays when it takes the current one, so that no refill waits for the atomic's round trip */
+#ifndef PT_POOL_AHEAD
+#define PT_POOL_AHEAD 0 /* measured equal to 0 at every pool size: the atomic's cost is its turn at the address, not its round trip */
 #endif
 /* idle lanes wait until this many can be refilled together */
 #ifndef PT_REFILL
@@ -330,6 +345,17 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *s
     const int n_rays = src.total();
     int pool_pos = 0, pool_end = 0; /* wave-uniform */
     bool exhausted = false;
+    /* The first PT_STATIC_NUM / PT_STATIC_DEN of the queue is dealt out without atomics: pool j * n_waves + w belongs to wavefront w
+     * (interleaved, so that every wavefront sees every part of the image), the rest goes through the cursor and evens out what the
+     * wavefronts' shares cost. */
+    const int n_waves = (int)gridDim.x * (TRACE_TPB / 64), wave_id = (int)blockIdx.x * (TRACE_TPB / 64) + (int)(threadIdx.x >> 6);
+    const int static_rounds = (int)(((long long)n_rays * PT_STATIC_NUM / PT_STATIC_DEN) / ((long long)n_waves * PT_POOL));
+    const int static_total = static_rounds * n_waves * PT_POOL;
+    int static_round = 0;
+#if PT_POOL_AHEAD
+    int next_base = 0; /* lane 0: the pool reserved ahead */
+    if (lane == 0) next_base = atomicAdd(src.counter, PT_POOL);
+#endif
 #if PT_PREFETCH
     int pf_acc = 0, pf_pending = 0; /* the first word of the nearest pushed sibling, loaded one visit ahead of its use */
 #endif
@@ -392,9 +418,20 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *s
          * sphere costs a double-precision quadratic) should run with many lanes, not one or two */
         if (idle && (__popcll(idle) >= PT_REFILL || __ballot(mode == TM_GEOM) == 0)) {
             if (pool_pos >= pool_end && !exhausted) {
+#if PT_POOL_AHEAD
+                /* the reservation made when the last pool was taken: its round trip is long over; the next one starts now */
+                const int base = __builtin_amdgcn_readfirstlane(next_base);
+                if (lane == 0) next_base = atomicAdd(src.counter, PT_POOL);
+#else
                 int base = 0;
-                if (lane == 0) base = atomicAdd(src.counter, PT_POOL);
-                base = __shfl(base, 0, 64);
+                if (static_round < static_rounds) { /* (wave-uniform) this wavefront's next pool of the dealt-out part: no atomic */
+                    base = (static_round * n_waves + wave_id) * PT_POOL;
+                    static_round++;
+                } else {
+                    if (lane == 0) base = atomicAdd(src.counter, PT_POOL);
+                    base = static_total + __shfl(base, 0, 64);
+                }
+#endif
                 if (base >= n_rays) exhausted = true;
                 else {
                     pool_pos = base;
@@ -629,12 +666,16 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *s
              * the lane that owns it, and makes the part of the test that does not depend on tMax (tri_cand); then every owner goes
              * through its leaf's triangles in their order and accepts each against the tMax it has by then (tri_cand_accept) -
              * the reference's sequence of tests, with the same values.  One round trip to the leaf records instead of up to four. */
-            const bool want = mode == TM_GEOM && node < 0 && !(PAIRS == PT_PAIRS_MIXED && in_cloud);
-            const unsigned long long wm = __ballot(want);
-            if (wm) {
+            for (int round_ = 0;; round_++) {
+                const bool want = mode == TM_GEOM && node < 0 && !(PAIRS == PT_PAIRS_MIXED && in_cloud);
+                const unsigned long long wm = __ballot(want);
+                if (!wm) break;
                 const unsigned packed = want ? (unsigned)(-(node + 1)) : 0u;
                 const int nm1 = (int)(packed >> 27); /* triangles in the leaf - 1 */
                 const unsigned long long c1m = __ballot(want && (nm1 & 1)), c2m = __ballot(want && (nm1 & 2));
+                /* another round at once (for the owners the first had no place for, and for those whose next stack entry is a leaf again)
+                 * only if it would be this full */
+                if (round_ > 0 && (PT_LEAF_REPEAT == 0 || __popcll(wm) + __popcll(c1m) + 2 * __popcll(c2m) < PT_LEAF_REPEAT)) break;
                 const int pre = __popcll(wm & lt_mask) + __popcll(c1m & lt_mask) + 2 * __popcll(c2m & lt_mask);
                 /* a round serves the owners whose pairs fit its 64 places (lowest lanes first); the others keep their leaf for the next */
                 const bool served = want && pre + nm1 < 64;
