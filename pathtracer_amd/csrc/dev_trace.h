@@ -30,6 +30,8 @@ struct TraceIO {
     char *prim, *face, *t, *b0, *b1;
     long long prim_es, face_es, t_es, b0_es, b1_es;
     int *counter; /* ray-fetch cursor, zero at launch */
+    int n_cursors; /* > 1: that many cursors, PT_CURSOR_STRIDE ints apart from `counter` on (all zero at launch), each over its own stretch
+                    * of the queue - atomics on one address are served one at a time, on different cache lines side by side (persistent_trace) */
     /* rays and results inside tiled word planes (dev_nee.h plane_at; the direct-light records):
      * tile_words = words per record (0: the byte strides above apply), o / prim = the plane base,
      * w_o, w_d, w_prim, w_t = first word of origin, direction, prim result, t result (-1: none) */
@@ -61,6 +63,11 @@ enum { TM_IDLE = 0, TM_TOP = 1, TM_TOPLEAF = 2, TM_GEOM = 3, TM_DONE = 4 /* CONT
 #ifndef PT_MIN_ACTIVE
 #define PT_MIN_ACTIVE 16 /* (8 before the leaf phase ran in pair mode: a leaf round is now cheap, leaving the node loop early costs less) */
 #endif
+/* ... in the build for scenes of many analytic primitives (the one with the wider top-level batch, rt_trace.hip), where few lanes are
+ * inside a mesh at any time: configs[2] 610 ms per step with 8, 625 with 16 */
+#ifndef PT_MIN_ACTIVE_WIDE
+#define PT_MIN_ACTIVE_WIDE 8
+#endif
 /* rays a wavefront reserves per atomic on the queue cursor */
 #ifndef PT_POOL
 #define PT_POOL 128 /* every wavefront of every launch adds to ONE cursor, and atomics on one address are served one at a time (~10 ns): at 64 rays per atomic the 361 K atomics of a 23 M-ray launch were 3.6 of its 5.5 ms.  configs[1] closest-hit launches per pass: 32 -> 55 ms, 64 -> 32.9, 128 -> 24.5, 256 -> 24.8, 512 -> 26.6, 1024 -> 30.5 (the rays a wavefront holds back at the end of a launch) */
@@ -78,6 +85,7 @@ enum { TM_IDLE = 0, TM_TOP = 1, TM_TOPLEAF = 2, TM_GEOM = 3, TM_DONE = 4 /* CONT
 #ifndef PT_LEAF_REPEAT
 #define PT_LEAF_REPEAT 16 /* configs[1], one pass alone: 125.3 ms with 0, 120.7 with 16 or 32, 121.0 with 48, 121.8 with 1 */
 #endif
+#define PT_CURSOR_STRIDE 16 /* ints between the cursors of a launch: a cache line each */
 /* the part of a launch's queue that is dealt out to the wavefronts without atomics (persistent_trace) */
 #ifndef PT_STATIC_NUM
 #define PT_STATIC_NUM 0 /* measured, configs[1], closest-hit launches per pass: 0 -> 25.5 ms, 1/2 -> 25.4, 3/4 -> 26.6, 7/8 -> 27.8 (pool 128); 3/4 -> 27.3, 15/16 -> 28.7 (pool 64): what the wavefronts' shares cost differs by more than the rest evens out */
@@ -153,7 +161,8 @@ struct OneSource {
     TraceIO io;
     int n_rays;
     int *counter;
-    PD void init() { n_rays = io.n_ptr ? *io.n_ptr : io.n; counter = io.counter; }
+    int n_cursors;
+    PD void init() { n_rays = io.n_ptr ? *io.n_ptr : io.n; counter = io.counter; n_cursors = io.n_cursors; }
     PD int total() const { return n_rays; }
     PD bool is_any(int) const { return ANY; }
     PD void fetch(int idx, int *tag, int *slot, f3 *ro, f3 *rd, float *tmax) const { *tag = 0; trace_io_fetch(io, idx, slot, ro, rd, tmax); }
@@ -169,11 +178,13 @@ struct ThreeSources {
     TraceIO path, shadow, mis; /* path.counter is the fetch cursor of the launch */
     int n0, n01, n012;
     int *counter;
+    int n_cursors;
     PD void init() {
         n0 = path.n_ptr ? *path.n_ptr : path.n;
         n01 = n0 + (shadow.n_ptr ? *shadow.n_ptr : shadow.n);
         n012 = n01 + (mis.n_ptr ? *mis.n_ptr : mis.n);
         counter = path.counter;
+        n_cursors = path.n_cursors;
     }
     PD int total() const { return n012; }
     PD bool is_any(int tag) const { return tag == 1; }
@@ -198,10 +209,12 @@ struct TwoAny {
     TraceIO a, b; /* a.counter is the fetch cursor of the launch */
     int n0, n01;
     int *counter;
+    int n_cursors;
     PD void init() {
         n0 = a.n_ptr ? *a.n_ptr : a.n;
         n01 = n0 + (b.n_ptr ? *b.n_ptr : b.n);
         counter = a.counter;
+        n_cursors = a.n_cursors;
     }
     PD int total() const { return n01; }
     PD bool is_any(int) const { return true; }
@@ -229,6 +242,7 @@ struct ChainSource {
     const int *n_ptr;
     int n_rays;
     int *counter;
+    static constexpr int n_cursors = 1;
     unsigned *probes; /* the kernel's per-lane count of probe rays */
     PD void init() { n_rays = *n_ptr; }
     PD int total() const { return n_rays; }
@@ -352,6 +366,11 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *s
     const int static_rounds = (int)(((long long)n_rays * PT_STATIC_NUM / PT_STATIC_DEN) / ((long long)n_waves * PT_POOL));
     const int static_total = static_rounds * n_waves * PT_POOL;
     int static_round = 0;
+    /* several cursors (TraceIO::n_cursors): the rest of the queue in that many stretches of whole pools; a wavefront starts on stretch
+     * wave_id mod n (so that the wavefronts of a block, and the blocks of a CU, spread over all of them) */
+    const int n_cursors = src.n_cursors > 1 ? src.n_cursors : 1;
+    const int seg_len = n_cursors > 1 ? (((n_rays - static_total) / n_cursors + PT_POOL) / PT_POOL) * PT_POOL : n_rays;
+    int cur_seg = n_cursors > 1 ? wave_id % n_cursors : 0, segs_empty = 0, seg_end = n_rays; /* wave-uniform */
 #if PT_POOL_AHEAD
     int next_base = 0; /* lane 0: the pool reserved ahead */
     if (lane == 0) next_base = atomicAdd(src.counter, PT_POOL);
@@ -427,6 +446,20 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *s
                 if (static_round < static_rounds) { /* (wave-uniform) this wavefront's next pool of the dealt-out part: no atomic */
                     base = (static_round * n_waves + wave_id) * PT_POOL;
                     static_round++;
+                } else if (n_cursors > 1) {
+                    /* the stretch this wavefront is working on, then - once that one has been found empty - the next, until all have */
+                    for (;;) {
+                        int got = 0;
+                        if (lane == 0) got = atomicAdd(src.counter + cur_seg * PT_CURSOR_STRIDE, PT_POOL);
+                        got = __builtin_amdgcn_readfirstlane(got);
+                        const int seg_begin = static_total + cur_seg * seg_len;
+                        seg_end = seg_begin + seg_len < n_rays ? seg_begin + seg_len : n_rays;
+                        base = seg_begin + got;
+                        if (got < seg_len && base < seg_end) break;
+                        base = n_rays;
+                        if (++segs_empty >= n_cursors) break;
+                        cur_seg = cur_seg + 1 == n_cursors ? 0 : cur_seg + 1;
+                    }
                 } else {
                     if (lane == 0) base = atomicAdd(src.counter, PT_POOL);
                     base = static_total + __shfl(base, 0, 64);
@@ -435,7 +468,7 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *s
                 if (base >= n_rays) exhausted = true;
                 else {
                     pool_pos = base;
-                    pool_end = base + PT_POOL < n_rays ? base + PT_POOL : n_rays;
+                    pool_end = base + PT_POOL < seg_end ? base + PT_POOL : seg_end;
                 }
             }
             const int avail = pool_end - pool_pos;
@@ -654,7 +687,7 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *s
 #if PT_SPEC
             }
 #endif
-            if (__popcll(__ballot(PT_IN_ACTIVE)) < PT_MIN_ACTIVE) break;
+            if (__popcll(__ballot(PT_IN_ACTIVE)) < (TOP_BATCH > PT_TOP_BATCH ? PT_MIN_ACTIVE_WIDE : PT_MIN_ACTIVE)) break;
         }
 
         /* ---- leaf ---- */

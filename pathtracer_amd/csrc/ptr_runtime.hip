@@ -441,7 +441,14 @@ struct ProfSpan {
  * of one overlaps the bulk of the others. */
 #define N_LANES 6 /* passes in flight (each on its own stream, ~5 GB of buffers at 16 M slots): 4 -> 6 gave +3.5 %, 8 no more */
 #define MAX_ITERS 20
-#define LANE_COUNTER_INTS (14 * MAX_ITERS)
+/* the fetch cursors of the pipeline's trace launches: three launches per bounce, PT_N_CURSORS cursors each on cache lines of their own */
+#ifndef PT_N_CURSORS
+#define PT_N_CURSORS 16
+#endif
+static int g_n_cursors = PT_N_CURSORS; /* PTR_CURSORS=1..PT_N_CURSORS (read by ptr_create): how many of them the launches use */
+#define LANE_CURSOR_BASE ((14 * MAX_ITERS + 15) / 16 * 16)
+#define LANE_CURSOR_INTS (PT_N_CURSORS * PT_CURSOR_STRIDE)
+#define LANE_COUNTER_INTS (LANE_CURSOR_BASE + 3 * MAX_ITERS * LANE_CURSOR_INTS)
 #define LANE_FB_COUNTS (10 * MAX_ITERS) /* fallback launches (fast top level, dev_trace.h): per bounce {count, cursor} of the path segments, then of the MIS rays */
 /* BSSRDF probe chains as tracer rays (rt_shade.h): the lane's counters for them, per staged bounce: [0] deferred vertices,
  * [1] chains that got a record, [2] the ray-fetch cursor of the chain launch, [4..8) k_route's counters over the exit-point
@@ -682,6 +689,7 @@ static void launch_ptrace(PtrContext *ctx, hipStream_t s, const TraceIO &io_in, 
         io2.n_ptr = fb_counters;
         io2.n = 0;
         io2.counter = fb_counters + 1;
+        io2.n_cursors = 0; /* (one cursor: the fallback queue is short) */
         io2.fb_queue = nullptr;
         io2.fb_count = nullptr;
         io2.is_fallback = 1;
@@ -733,6 +741,7 @@ static TraceIO path_io(const Lane &l, const int *queue, const int *n_ptr, int n_
     io.hit16 = l.pipe.hit;
     io.n_ptr = n_ptr;
     io.counter = cursor;
+    io.n_cursors = cursor ? g_n_cursors : 0;
     return io;
 }
 /* any hit within (0, 1 - ShadowEpsilon); closest = true: the first hit (primitive into occA, distance into tA) */
@@ -745,6 +754,7 @@ static TraceIO shadow_io(const Lane &l, const int *queue, const int *n_ptr, int 
     io.tmax_const = 1 - 0.0001f;
     io.prim = (char *)l.pipe.nee; io.w_prim = WORD_OF(NeeRec, occA); io.w_t = closest ? WORD_OF(NeeRec, tA) : -1;
     io.counter = cursor;
+    io.n_cursors = cursor ? g_n_cursors : 0;
     return io;
 }
 static TraceIO mis_io(const Lane &l, const int *queue, const int *n_ptr, int *cursor) { /* closest hit */
@@ -756,6 +766,7 @@ static TraceIO mis_io(const Lane &l, const int *queue, const int *n_ptr, int *cu
     io.tmax_const = FLT_MAX;
     io.prim = (char *)l.pipe.nee; io.w_prim = WORD_OF(NeeRec, hitB); io.w_t = WORD_OF(NeeRec, tB);
     io.counter = cursor;
+    io.n_cursors = cursor ? g_n_cursors : 0;
     return io;
 }
 /* Direct light at the exit points as records of the tracer's launches?  Not where its rays may pass through primitives (the
@@ -955,18 +966,19 @@ static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int ste
     const bool nee_closest = integrator == PTR_LI_VOLPATH && !ctx->scene_all_opaque && !ctx->scene_passthrough && ctx->nee_closest_ok;
     const bool walks = integrator == PTR_LI_VOLPATH && !ctx->scene_all_opaque && !nee_closest;
     prm.nee_p1 = walks ? 1 : 0;
-    int *cursors = l.counts + 4 * MAX_ITERS; /* ray-fetch cursors of the trace launches, 3 per bounce */
+    int *const cursor_base = l.counts + LANE_CURSOR_BASE; /* ray-fetch cursors of the trace launches, 3 sets per bounce */
+    auto cursors_of = [&](int i) { return cursor_base + (size_t)i * LANE_CURSOR_INTS; };
     auto upper_at = [&](int k) { int u = slots >> (k < 6 ? k : 6); return u < 1 ? 1 : u; };
     if (!walks && !nee_closest && ctx->merge_traces) {
         /* per bounce: shade, then ONE trace launch for the rays it made - the next path segments, the
          * shadow rays and the MIS rays - then the direct-light sum (before the next shade adds emission) */
-        launch_ptrace(ctx, s, path_io(l, nullptr, nullptr, slots, cursors + 0), slots, false, ctx->count_traversal, K_TRACE);
+        launch_ptrace(ctx, s, path_io(l, nullptr, nullptr, slots, cursors_of(0)), slots, false, ctx->count_traversal, K_TRACE);
         for (int k = 0; k < staged; k++) {
             int *q_next = l.queues[qi];
             int *cnt = l.counts + 4 * k;
             enqueue_shade(ctx, l, prm, k == 0 ? nullptr : l.counts + 4 * (k - 1), slots, upper_at(k), q_cur, q_next, k);
             const bool more = k + 1 < staged; /* after the last staged bounce the finish kernel traces the survivors itself */
-            TraceIO p = path_io(l, q_next, more ? cnt + 0 : nullptr, 0, cursors + 3 * k + 1);
+            TraceIO p = path_io(l, q_next, more ? cnt + 0 : nullptr, 0, cursors_of(3 * k + 1));
             const int n_upper = (more ? upper_at(k + 1) : 0) + 2 * upper_at(k);
             {
                 ProfScope ps(ctx, s, K_TRACE, 0);
@@ -984,7 +996,7 @@ static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int ste
             int *q_next = l.queues[qi];
             const int *n_ptr = k == 0 ? nullptr : l.counts + 4 * (k - 1);
             int *fbc = l.counts + LANE_FB_COUNTS + 4 * k; /* {count, cursor} for the path segments, then for the MIS rays */
-            launch_ptrace(ctx, s, path_io(l, q_cur, n_ptr, slots, cursors + 3 * k), upper_at(k), false, ctx->count_traversal, K_TRACE, est[k][0], l.fb_queue, fbc);
+            launch_ptrace(ctx, s, path_io(l, q_cur, n_ptr, slots, cursors_of(3 * k)), upper_at(k), false, ctx->count_traversal, K_TRACE, est[k][0], l.fb_queue, fbc);
             STAGE_CHECK("trace");
             enqueue_shade(ctx, l, prm, n_ptr, slots, upper_at(k), q_cur, q_next, k);
             STAGE_CHECK("miss / shade / route");
@@ -993,13 +1005,13 @@ static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int ste
                 int *cnt = l.counts + 4 * k;
                 /* The BSDF-sampled half of EstimateDirect asks what the ray hits first; when no primitive can emit and no
                  * medium can attenuate, all nee_resolve_traced reads from the answer is whether anything was hit: any hit will do. */
-                TraceIO mio = mis_io(l, l.queues[4], cnt + 3, cursors + 3 * k + 2);
+                TraceIO mio = mis_io(l, l.queues[4], cnt + 3, cursors_of(3 * k + 2));
                 const bool mis_any = ctx->mis_any_hit && ctx->scene_all_opaque && !ctx->scene_has_media;
                 mio.any_as_hit = mis_any ? 1 : 0;
                 if (mis_any && ctx->nee_one_launch && !ctx->count_traversal) { /* (the counting pass of bench.py wants a launch per ray kind) */
                     ProfScope ps(ctx, s, K_SHADOW, 0);
                     (use_quad(ctx, 2ll * upper_at(k)) ? rt_launch_qtrace2any : rt_launch_ptrace2any)(trace_blocks(ctx, 2ll * upper_at(k)), s,
-                                                                                     ctx->sc, shadow_io(l, l.queues[3], cnt + 2, cursors + 3 * k + 1), mio);
+                                                                                     ctx->sc, shadow_io(l, l.queues[3], cnt + 2, cursors_of(3 * k + 1)), mio);
                 } else if (exit_records(ctx, l, integrator) && !ctx->count_traversal) {
                     /* scenes with a BSSRDF material: the rays of the exit-point records ride in the same launches (any hit + any hit
                      * in one TwoAny launch; a closest-hit MIS launch gets a second launch for them) */
@@ -1007,7 +1019,7 @@ static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int ste
                     mio2.any_as_hit = mis_any ? 1 : 0;
                     {
                         ProfScope ps(ctx, s, K_SHADOW, 0);
-                        rt_launch_ptrace2any(trace_blocks(ctx, 2ll * upper_at(k)), s, ctx->sc, shadow_io(l, l.queues[3], cnt + 2, cursors + 3 * k + 1), exit_io(l, k, false));
+                        rt_launch_ptrace2any(trace_blocks(ctx, 2ll * upper_at(k)), s, ctx->sc, shadow_io(l, l.queues[3], cnt + 2, cursors_of(3 * k + 1)), exit_io(l, k, false));
                     }
                     if (mis_any) {
                         ProfScope ps(ctx, s, K_MIS_ANY, 0);
@@ -1017,7 +1029,7 @@ static int run_pass(PtrContext *ctx, Lane &l, int lane_index, int first, int ste
                         launch_ptrace(ctx, s, mio2, upper_at(k), false, false, K_MIS);
                     }
                 } else {
-                launch_ptrace(ctx, s, shadow_io(l, l.queues[3], cnt + 2, cursors + 3 * k + 1, nee_closest), upper_at(k), !nee_closest, ctx->count_traversal, K_SHADOW, est[k][1]);
+                launch_ptrace(ctx, s, shadow_io(l, l.queues[3], cnt + 2, cursors_of(3 * k + 1), nee_closest), upper_at(k), !nee_closest, ctx->count_traversal, K_SHADOW, est[k][1]);
                 launch_ptrace(ctx, s, mio, upper_at(k), mis_any, ctx->count_traversal, mis_any ? K_MIS_ANY : K_MIS, est[k][2], l.fb_queue, fbc + 2);
                 if (exit_records(ctx, l, integrator)) { /* (counting pass: a launch per ray kind) */
                     TraceIO mio2 = exit_io(l, k, true);
@@ -1131,6 +1143,7 @@ int ptr_create(int device, PtrContext **out) {
     /* persistent grid: enough 256-thread blocks to fill every CU at the tracer's occupancy */
     ctx->n_cus = prop.multiProcessorCount;
     ctx->persist_blocks = prop.multiProcessorCount * PT_WAVES;
+    if (const char *e = getenv("PTR_CURSORS")) { int v = atoi(e); if (v >= 1 && v <= PT_N_CURSORS) g_n_cursors = v; }
     if (const char *e = getenv("PTR_TRACE_WAVES")) { int v = atoi(e); if (v == PT_WAVES || v == PT_WAVES_WIDE || v == PT_WAVES_LEAN) ctx->trace_waves_forced = v; }
     if (const char *e = getenv("PTR_TRACE_LEAN")) ctx->trace_lean = atoi(e) != 0;
     if (const char *e = getenv("PTR_TRACE_WIDE_FROM")) { int v = atoi(e); if (v >= 0) ctx->wide_from = v; }

@@ -47,7 +47,9 @@
  * configs[1]: 6.44 -> 6.2 ms per closest-hit launch). */
 /* Pair mode (dev_trace.h): the leaf phase deals (ray, triangle) pairs to all lanes; 64 bytes of LDS per wavefront for the round's pair
  * list.  The lean build serves scenes of triangle meshes and analytic primitives only (ptr_runtime.hip picks it for scenes without SDF
- * shapes and without particle clouds); the others keep the item loop for the leaves of clouds.  PT_PAIRS: 0 none, 1 the lean build, 2 all. */
+ * shapes and without particle clouds); the others keep the item loop for the leaves of clouds (configs[2], 6 % of whose tracer time is
+ * spent in meshes: 601-615 ms per step with pair mode in its four-wave build, 623-628 without; configs[4]: 1948 against 1832 Mrays/s).
+ * PT_PAIRS: 0 none, 1 the lean build, 2 all. */
 #ifndef PT_PAIRS
 #define PT_PAIRS 2
 #endif
@@ -152,14 +154,15 @@ k_pchain(DScene sc, uint32_t *planes, const int *n_ptr, int *cursor, unsigned lo
     __shared__ int s_stack[LDS_STACK * TRACE_TPB];
     PT_STAGED_NODES(sc);
     PT_STAGED_TOP(sc, false, TOP_LDS_NODES);
-    PT_PAIR_LIST(PCHAIN_WAVES);
+    __shared__ unsigned char s_pairs[PT_PAIRS ? TRACE_TPB : 1]; /* (pair mode whatever PCHAIN_WAVES is: a probe ray's time is spent in the mesh it probes) */
+    unsigned char *const pair_list = PT_PAIRS ? &s_pairs[threadIdx.x & ~63u] : nullptr;
     unsigned tn = 0, ti = 0, probes = 0;
     ChainSource src;
     src.planes = planes;
     src.n_ptr = n_ptr;
     src.counter = cursor;
     src.probes = &probes;
-    persistent_trace<ChainSource, false, false, TOP_LDS_NODES, PT_TOP_BATCH, true, PT_PAIRS_OF(PCHAIN_WAVES)>(sc, src, &s_stack[threadIdx.x], s_staged, s_top, &tn, &ti, pair_list);
+    persistent_trace<ChainSource, false, false, TOP_LDS_NODES, PT_TOP_BATCH, true, PT_PAIRS ? PT_PAIRS_MIXED : PT_PAIRS_OFF>(sc, src, &s_stack[threadIdx.x], s_staged, s_top, &tn, &ti, pair_list);
     ctr_flush(ctrs, C_PROBE, probes);
 }
 void rt_launch_pchain(unsigned blocks, hipStream_t s, const DScene &sc, uint32_t *planes, const int *n_ptr, int *cursor, unsigned long long *ctrs) {
