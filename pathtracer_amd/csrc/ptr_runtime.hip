@@ -439,7 +439,11 @@ struct ProfSpan {
  * Ray cost is heavy-tailed - a launch over a few hundred late-bounce rays still lasts as long as
  * its longest ray, ~1 ms of dependent loads - so several passes are kept in flight and the tail
  * of one overlaps the bulk of the others. */
-#define N_LANES 6 /* passes in flight (each on its own stream, ~5 GB of buffers at 16 M slots): 4 -> 6 gave +3.5 %, 8 no more */
+#define N_LANES 6 /* passes in flight at most (PTR_LANES; each on its own stream) */
+/* ... and by default.  Six in rounds 1-3 (4 -> 6 gave +3.5 % then); since the tracer's launches stopped queueing up on their fetch
+ * cursor (dev_trace.h PT_POOL) three do as much - configs[1] 2321 Mrays/s with six, 2328 with three; configs[3] 2903 / 3160,
+ * configs[5] 6149 / 6416, configs[0] and [4] equal - and only they get pass buffers: 59 GB at 1080p instead of 118. */
+#define PT_LANES_DEFAULT 3
 #define MAX_ITERS 20
 /* the fetch cursors of the pipeline's trace launches: three launches per bounce, PT_N_CURSORS cursors each on cache lines of their own */
 #ifndef PT_N_CURSORS
@@ -532,7 +536,8 @@ struct PtrContext {
     /* pipeline */
     Lane lanes[N_LANES];
     int next_lane = 0, last_film_lane = -1;
-    int lanes_used = N_LANES; /* passes kept in flight (PTR_LANES=1..N_LANES; else chosen per scene at upload) */
+    int lanes_alloc = PT_LANES_DEFAULT; /* lanes that get pass buffers (PTR_LANES=1..N_LANES) */
+    int lanes_used = PT_LANES_DEFAULT; /* passes kept in flight: lanes_alloc, or fewer, chosen per scene at upload */
     bool lanes_forced = false;
     int staged_bounces = 6; /* wavefront bounces before k_finish; adapted from the live counts of finished passes */
     bool staged_fixed = false;
@@ -1164,7 +1169,7 @@ int ptr_create(int device, PtrContext **out) {
     if (const char *e = getenv("PTR_SSS_CHAINS")) ctx->sss_rounds = atoi(e) != 0 ? 1 : 0;
     if (const char *e = getenv("PTR_SSS_CAP_DIV")) { int v = atoi(e); if (v >= 1) ctx->sss_cap_div = v; }
     if (const char *e = getenv("PTR_SSS_EXIT")) ctx->sss_exit_records = atoi(e) != 0;
-    if (const char *e = getenv("PTR_LANES")) { int v = atoi(e); if (v >= 1 && v <= N_LANES) { ctx->lanes_used = v; ctx->lanes_forced = true; } }
+    if (const char *e = getenv("PTR_LANES")) { int v = atoi(e); if (v >= 1 && v <= N_LANES) { ctx->lanes_used = ctx->lanes_alloc = v; ctx->lanes_forced = true; } }
     if (const char *e = getenv("PTR_SPREAD")) { /* tuning experiments */
         int v = atoi(e);
         if (v > 0) ctx->spread = v;
@@ -1446,7 +1451,7 @@ int ptr_scene_upload_built(PtrContext *ctx, const PtrBuiltScene *built) {
          * (a top level of a hundred analytic primitives) there is no tail to speak of and the passes only take each other's
          * cache: configs[2] 671 ms per step with six, 654 with four, 641 with two, 639 with one (configs[0], [1], [5]: six is
          * best; [3], [4]: three and six within 3 %). */
-        if (!ctx->lanes_forced) ctx->lanes_used = analytic >= 32 ? 2 : N_LANES;
+        if (!ctx->lanes_forced) ctx->lanes_used = analytic >= 32 && ctx->lanes_alloc > 2 ? 2 : ctx->lanes_alloc;
     }
     sc.n_nodes = (int)hs.nodes.size();
     sc.n_items = (int)hs.items.size();
@@ -1492,7 +1497,8 @@ static hipError_t alloc_lanes(PtrContext *ctx, int npix, int nb) {
     const size_t cap_tiles = ((cap + ((size_t)1 << PLANE_TILE_SHIFT) - 1) >> PLANE_TILE_SHIFT) << PLANE_TILE_SHIFT; /* whole tiles */
     hipError_t e = hipSuccess;
 #define TRY(expr) do { if (e == hipSuccess) e = (expr); } while (0)
-    for (Lane &l : ctx->lanes) {
+    for (int li = 0; li < ctx->lanes_alloc; li++) {
+        Lane &l = ctx->lanes[li];
         TRY(hipMalloc((void **)&l.pipe.ro, 3 * sizeof(float) * cap));
         TRY(hipMalloc((void **)&l.pipe.rd, 3 * sizeof(float) * cap));
         TRY(hipMalloc((void **)&l.pipe.hit, sizeof(int4) * cap));
@@ -1547,7 +1553,7 @@ int ptr_film_init(PtrContext *ctx, int width, int height, uint64_t seed) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             const double budget = 0.9 * (double)free_b;
-            while (nb > 1 && (double)npix * nb * (double)lane_bytes_per_slot() * N_LANES > budget) nb = (nb + 1) / 2;
+            while (nb > 1 && (double)npix * nb * (double)lane_bytes_per_slot() * ctx->lanes_alloc > budget) nb = (nb + 1) / 2;
         }
         for (;;) {
             e = alloc_lanes(ctx, npix, nb);

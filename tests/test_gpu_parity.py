@@ -339,7 +339,7 @@ def test_film_init_shrinks_and_recovers(scenes):
     r.sync()
     want = r.film()
     free0 = torch.cuda.mem_get_info()[0]
-    # 4096 x 4096 pixels x 64 samples would be 2^30 slots x 300 B x 6 lanes = 1.9 TB: must shrink (to at most 2^29 slots, then to what is free)
+    # 4096 x 4096 pixels x 64 samples would be 2^30 slots x 308 B x 3 lanes = 0.99 TB: must shrink (to at most 2^29 slots, then to what is free)
     old = os.environ.get("PTR_PASS_SLOTS")
     os.environ["PTR_PASS_SLOTS"] = str(1 << 40)
     try:
@@ -352,10 +352,15 @@ def test_film_init_shrinks_and_recovers(scenes):
         got = r.film()
         for a, b in zip(want, got):
             assert np.array_equal(a, b)
-        # a film whose pass buffers cannot exist even at one sample per pass (2^28 pixels x 300 B x 6 lanes = 483 GB):
-        # an error, and nothing stays allocated
-        with pytest.raises(pa.capi.PtrError):
-            r.film_init(16384, 16384, SEED)
+        # a film whose pass buffers cannot exist even at one sample per pass (2^28 pixels x 308 B x 3 lanes = 248 GB, with
+        # 60 % of the device taken by someone else): an error, and nothing stays allocated
+        hog = torch.empty(int(free0 * 0.6), dtype=torch.uint8, device="cuda")
+        try:
+            with pytest.raises(pa.capi.PtrError):
+                r.film_init(16384, 16384, SEED)
+        finally:
+            del hog
+            torch.cuda.empty_cache()
         assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)
     finally:
         if old is None:
