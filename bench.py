@@ -51,13 +51,28 @@ CONFIGS = {
 
 
 def newest_summary():
+    """The committed PMC summary that was collected from THIS tree's kernel sources (`_csrc_hash`), the last by name if there are
+    several; else the last by name (measured_traffic then reports null: stale counters are not quoted)."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")))
     if not files:
         return None, None
-    try:
-        return json.load(open(files[-1])), os.path.relpath(files[-1], ROOT)
-    except Exception:
+    loaded = []
+    for f in files:
+        try:
+            loaded.append((json.load(open(f)), os.path.relpath(f, ROOT)))
+        except Exception:
+            pass
+    if not loaded:
         return None, None
+    try:
+        from pathtracer_amd.capi import kernel_source_hash
+        h = kernel_source_hash()
+        fresh = [x for x in loaded if x[0].get("_csrc_hash") == h]
+        if fresh:
+            return fresh[-1]
+    except Exception:
+        pass
+    return loaded[-1]
 
 
 def measured_traffic(summary, kernel, config):
