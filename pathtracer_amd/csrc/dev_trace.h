@@ -97,6 +97,14 @@ enum { TM_IDLE = 0, TM_TOP = 1, TM_TOPLEAF = 2, TM_GEOM = 3, TM_DONE = 4 /* CONT
 #ifndef PT_POOL_AHEAD
 #define PT_POOL_AHEAD 0 /* measured equal to 0 at every pool size: the atomic's cost is its turn at the address, not its round trip */
 #endif
+/* top level: a leaf that holds nothing more is left, and a walk whose stack has run out is ended, in the step that finds it so
+ * instead of in steps of their own (6 -> 3-4 wave iterations per ray in a scene of two primitives; same tests, same order, films
+ * identical).  0 never, 1 always, 2 in the build for scenes of many analytic primitives only (the one with the wider top-level batch):
+ * configs[2] 593.8 -> 585.5 ms per step, configs[0] and [5] equal, but configs[1] 104.0 -> 109.2 ms per pass (the any-hit launches
+ * +2 ms each way: lanes that leave a mesh join the top-level batch a step earlier and it runs with fewer of them) */
+#ifndef PT_TOP_FUSE
+#define PT_TOP_FUSE 2
+#endif
 /* idle lanes wait until this many can be refilled together */
 #ifndef PT_REFILL
 #define PT_REFILL 24
@@ -336,6 +344,7 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *s
 #endif
     const int lane = __lane_id();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    constexpr bool TOP_FUSE = PT_TOP_FUSE == 1 || (PT_TOP_FUSE == 2 && TOP_BATCH > PT_TOP_BATCH);
 
     int mode = TM_IDLE, slot = -1, tag = 0;
     src.init();
@@ -400,10 +409,29 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *s
         slot = -1;                                                                   \
     } while (0)
 /* the ray leaves a mesh / cloud: a hit it took there becomes the bound for what follows */
+/* the walk has ended (the stack's bottom entry came up) */
+#define PT_TOP_END()                                                                 \
+    do {                                                                             \
+        bool dfr_ = false;                                                           \
+        if (PT_FZ_CLOSEST && hit) {                                                  \
+            /* a mesh / cloud winner: would the reference have reached it?  (an analytic winner: G says so) */ \
+            const DPrim &pw = sc.prims[hp];                                          \
+            float te;                                                                \
+            if ((pw.type == SH_MESH || pw.type == SH_CLOUD) &&                       \
+                !slab_test6(pw.bmin[0], pw.bmin[1], pw.bmin[2], pw.bmax[0], pw.bmax[1], pw.bmax[2], ro, inv, tbest, &te)) dfr_ = true; \
+            else tmax = tbest;                                                       \
+        }                                                                            \
+        if (dfr_) PT_DEFER();                                                        \
+        else PT_FINISH();                                                            \
+    } while (0)
 #define PT_LEAVE_GEOM()                                                              \
     do {                                                                             \
         if (PT_FZ_CLOSEST && hit && hp == cp) tmax = tbest * FZ_WIDEN;               \
-        mode = TM_TOPLEAF;                                                           \
+        if (TOP_FUSE && leaf_pos == tnode) { /* ... and its top-level leaf, which holds nothing more: the pop now, not in a step of its own */ \
+            tnode = PT_POP();                                                        \
+            fresh = false;                                                           \
+            mode = TM_TOP;                                                           \
+        } else mode = TM_TOPLEAF;                                                    \
     } while (0)
 
     for (;;) {
@@ -511,18 +539,7 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *s
             bool leaf_box = false; /* ... after its leaf's box, which is the primitive's own bounds */
             if (mode == TM_TOP) {
                 if (tnode == -1) {
-                    if (PT_FZ_CLOSEST && hit) {
-                        /* a mesh / cloud winner: would the reference have reached it?  (an analytic winner: G says so) */
-                        const DPrim &pw = sc.prims[hp];
-                        float te;
-                        if ((pw.type == SH_MESH || pw.type == SH_CLOUD) &&
-                            !slab_test6(pw.bmin[0], pw.bmin[1], pw.bmin[2], pw.bmax[0], pw.bmax[1], pw.bmax[2], ro, inv, tbest, &te)) {
-                            PT_DEFER();
-                            break;
-                        }
-                        tmax = tbest;
-                    }
-                    PT_FINISH();
+                    PT_TOP_END();
                     break;
                 }
                 if (tnode < -1) {
@@ -636,7 +653,16 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *s
                         hp = p; hf = face; if (Source::BARY) { hb0 = 0; hb1 = 0; } hit = true;
                         if (PT_ANY) { PT_FINISH(); break; }
                     }
+                    if (TOP_FUSE && leaf_pos == tnode) { /* the leaf holds nothing more: the pop now, not in a step of its own */
+                        tnode = PT_POP();
+                        fresh = false;
+                        mode = TM_TOP;
+                    }
                 }
+            }
+            if (TOP_FUSE && mode == TM_TOP && tnode == -1) { /* ... and the end of the walk in the step whose pop brought it up */
+                PT_TOP_END();
+                break;
             }
         }
 
@@ -862,6 +888,7 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *s
 #undef PT_FZ_CLOSEST
 #undef PT_DEFER
 #undef PT_LEAVE_GEOM
+#undef PT_TOP_END
 }
 
 /* ---- fullest-phase-first scheduling -------------------------------------------------------------------
