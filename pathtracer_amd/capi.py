@@ -273,13 +273,14 @@ def check(rc):
 
 
 def kernel_source_hash():
-    """sha256 over the kernel sources (csrc/*, sorted by name) the built library comes from: profiles/*_summary.json records
+    """sha256 over the kernel sources (csrc/*, sorted by name) and the Makefile (compile flags) the built library comes from: profiles/*_summary.json records
     it when counters are collected, and bench.py reports counter traffic only from a summary whose hash is this tree's."""
     import glob
     import hashlib
 
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "*"))):
+    here = os.path.dirname(os.path.abspath(__file__))
+    for f in sorted(glob.glob(os.path.join(here, "csrc", "*"))) + [os.path.join(here, "Makefile")]:
         if os.path.isfile(f):
             h.update(os.path.basename(f).encode())
             h.update(open(f, "rb").read())
