@@ -58,7 +58,11 @@ template <int W0, int W1, typename T> PD void soa_load(const uint32_t *base, int
 template <int W0, int W1, typename T> PD void soa_store(uint32_t *base, int cap, int slot, const T *rec) {
     const uint32_t *o = reinterpret_cast<const uint32_t *>(rec);
 #pragma unroll
+#if PT_NT_RECORDS >= 2
+    for (int w = W0; w < W1; w++) __builtin_nontemporal_store(o[w], &base[plane_at((int)(sizeof(T) / 4), slot, w)]);
+#else
     for (int w = W0; w < W1; w++) base[plane_at((int)(sizeof(T) / 4), slot, w)] = o[w];
+#endif
 }
 #define NEE_A_BEGIN WORD_OF(NeeRec, fA)
 #define NEE_A_END WORD_OF(NeeRec, fB)
