@@ -93,10 +93,6 @@ enum { TM_IDLE = 0, TM_TOP = 1, TM_TOPLEAF = 2, TM_GEOM = 3, TM_DONE = 4 /* CONT
 #ifndef PT_STATIC_DEN
 #define PT_STATIC_DEN 4
 #endif
-/* a wavefront reserves its next pool of rays when it takes the current one, so that no refill waits for the atomic's round trip */
-#ifndef PT_POOL_AHEAD
-#define PT_POOL_AHEAD 0 /* measured equal to 0 at every pool size: the atomic's cost is its turn at the address, not its round trip */
-#endif
 /* top level: a leaf that holds nothing more is left, and a walk whose stack has run out is ended, in the step that finds it so
  * instead of in steps of their own (6 -> 3-4 wave iterations per ray in a scene of two primitives; same tests, same order, films
  * identical).  0 never, 1 always, 2 in the build for scenes of many analytic primitives only (the one with the wider top-level batch):
@@ -380,10 +376,6 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *s
     const int n_cursors = src.n_cursors > 1 ? src.n_cursors : 1;
     const int seg_len = n_cursors > 1 ? (((n_rays - static_total) / n_cursors + PT_POOL) / PT_POOL) * PT_POOL : n_rays;
     int cur_seg = n_cursors > 1 ? wave_id % n_cursors : 0, segs_empty = 0, seg_end = n_rays; /* wave-uniform */
-#if PT_POOL_AHEAD
-    int next_base = 0; /* lane 0: the pool reserved ahead */
-    if (lane == 0) next_base = atomicAdd(src.counter, PT_POOL);
-#endif
 #if PT_PREFETCH
     int pf_acc = 0, pf_pending = 0; /* the first word of the nearest pushed sibling, loaded one visit ahead of its use */
 #endif
@@ -465,11 +457,6 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *s
          * sphere costs a double-precision quadratic) should run with many lanes, not one or two */
         if (idle && (__popcll(idle) >= PT_REFILL || __ballot(mode == TM_GEOM) == 0)) {
             if (pool_pos >= pool_end && !exhausted) {
-#if PT_POOL_AHEAD
-                /* the reservation made when the last pool was taken: its round trip is long over; the next one starts now */
-                const int base = __builtin_amdgcn_readfirstlane(next_base);
-                if (lane == 0) next_base = atomicAdd(src.counter, PT_POOL);
-#else
                 int base = 0;
                 if (static_round < static_rounds) { /* (wave-uniform) this wavefront's next pool of the dealt-out part: no atomic */
                     base = (static_round * n_waves + wave_id) * PT_POOL;
@@ -492,7 +479,6 @@ PD void persistent_trace(const DScene &sc, Source src, int *lds, const float4 *s
                     if (lane == 0) base = atomicAdd(src.counter, PT_POOL);
                     base = static_total + __shfl(base, 0, 64);
                 }
-#endif
                 if (base >= n_rays) exhausted = true;
                 else {
                     pool_pos = base;
