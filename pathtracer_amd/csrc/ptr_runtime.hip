@@ -1148,6 +1148,7 @@ int ptr_create(int device, PtrContext **out) {
     /* persistent grid: enough 256-thread blocks to fill every CU at the tracer's occupancy */
     ctx->n_cus = prop.multiProcessorCount;
     ctx->persist_blocks = prop.multiProcessorCount * PT_WAVES;
+    g_n_cursors = PT_N_CURSORS; /* (process-wide, like the other tuning hooks of the trace launches: the last ptr_create decides) */
     if (const char *e = getenv("PTR_CURSORS")) { int v = atoi(e); if (v >= 1 && v <= PT_N_CURSORS) g_n_cursors = v; }
     if (const char *e = getenv("PTR_TRACE_WAVES")) { int v = atoi(e); if (v == PT_WAVES || v == PT_WAVES_WIDE || v == PT_WAVES_LEAN) ctx->trace_waves_forced = v; }
     if (const char *e = getenv("PTR_TRACE_LEAN")) ctx->trace_lean = atoi(e) != 0;
