@@ -1444,8 +1444,12 @@ int ptr_scene_upload_built(PtrContext *ctx, const PtrBuiltScene *built) {
         /* ... and the builds without the SDF shapes' code where there is no SDF shape and the top level is small: six waves per SIMD,
          * five where particle clouds bring their double-precision quadratic (configs[3]: 111.6 ms per step with five, 114.6 with six,
          * 116.7 with the SDF code; configs[1]: 119.5 / 117.0 / 124.0) */
+        /* (the four-wave build carries the SDF code: a scene of a few analytic primitives and no SDF shape - spheres around a mesh, a glass
+         * sphere in a medium - is better off with the five-wave build without it: configs[4] 82.6 -> 80.7 ms per step, configs[5] 212.8 -> 205.6;
+         * from 32 analytic primitives on the top level is most of a ray's work and the four-wave build's wider batch and LDS copy win) */
+        const bool wide = analytic >= ctx->wide_from && (sc.has_proc || analytic >= 32);
         sc.trace_waves = ctx->trace_waves_forced ? ctx->trace_waves_forced
-                                                 : (analytic >= ctx->wide_from ? PT_WAVES_WIDE : (!sc.has_proc && !clouds ? PT_WAVES_LEAN : PT_WAVES));
+                                                 : (wide ? PT_WAVES_WIDE : (!sc.has_proc && !clouds && analytic < ctx->wide_from ? PT_WAVES_LEAN : PT_WAVES));
         if (sc.trace_waves == PT_WAVES_LEAN && (sc.has_proc || clouds)) sc.trace_waves = PT_WAVES; /* (forced: the lean build has neither the SDF shapes' code nor, in pair mode, the particles') */
         if (!ctx->persist_blocks_forced) ctx->persist_blocks = ctx->n_cus * sc.trace_waves;
         /* Passes in flight.  Six overlap the tail of one pass's launches with the bulk of another's; where a launch lasts 15-20 ms
